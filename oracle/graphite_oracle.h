@@ -1,0 +1,73 @@
+/*
+ * graphite_oracle.h -- CPU restatement of GRAPHITE's transform-robustness scoring path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing under graphite_amd/ (the product) may include,
+ * link, load or call this; only tests/, __graft_entry__.smoke() and bench.py's
+ * cpu_baseline leg use it, as the checker / the timed CPU baseline.
+ *
+ * PARITY STATUS
+ *  - Host geometry (transform sampling, homography, crop), score_fn, run_predictions
+ *    batching and the classifier layers are PINNED against outputs of the reference's
+ *    own Python run in the build container (tests/golden/make_golden.py).
+ *  - The pixel arithmetic the reference delegates to opencv-python==4.2.0.32
+ *    (requirements.txt:4; cv2.resize, cv2.GaussianBlur, cv2.warpPerspective, cv2.LUT --
+ *    transforms.py:23,56,73,148,151; perspective_transform.py:47) is restated from the
+ *    published OpenCV 4.2 algorithm.  OpenCV is neither vendored nor installed and the
+ *    reference has no tests or pixel fixtures: PARITY UNPINNED at that boundary.
+ *
+ * All images are planar CHW float32 (the reference converts CHW<->HWC around every
+ * cv2 call; per-channel arithmetic is identical).
+ */
+#ifndef GRAPHITE_ORACLE_H
+#define GRAPHITE_ORACLE_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Same layout as gr_xform in include/graphite_hip.h. */
+typedef struct or_xform {
+    double M[9];            /* FORWARD src->dst homography, as passed to cv2.warpPerspective */
+    int32_t crop_x, crop_y; /* dsize */
+    int32_t blur;           /* 0,3,5,7 */
+    int32_t pad_;
+    uint8_t lut[256];       /* gamma table, transforms.py:70-72 */
+} or_xform;
+
+/* cv2.resize(src,(dw,dh)) INTER_LINEAR on C planes. */
+int or_resize_linear(const float* src, int C, int sh, int sw, float* dst, int dh, int dw);
+
+/* transforms.py:143-159.  Any of comb/pert/mask_lg may be NULL. */
+int or_add_noise(const float* img, int H, int W, const float* mask, const float* theta, int nh, int nw,
+                 float lbd, int clip, float* comb, float* pert, float* mask_lg);
+
+/* transforms.py:55-62: GaussianBlur(pert,(k,k),0) -> where(mask_lg>0.5, pert, img) -> clip. */
+int or_composite(const float* img, const float* pert, const float* mask_lg, int H, int W, int blur, float* att);
+
+/* perspective_transform.py:47 + transforms.py:69-77: warpPerspective(BORDER_REPLICATE) -> u8 -> LUT
+ * -> /255 -> resize(net,net) -> clamp -> (-0.5 if normalize).  out = [3,net,net].
+ * If warped != NULL it receives the full [3,crop_y,crop_x] warp (before the uint8 stage). */
+int or_warp_one(const float* att, int H, int W, const or_xform* xf, int normalize, int net, float* out,
+                float* warped);
+
+/* get_transformed_images for C candidates x T transforms: out = [C,T,3,net,net]. */
+int or_warp_batch(const float* img, int H, int W, const float* masks, const float* thetas, int C, int nh, int nw,
+                  const or_xform* xf, int T, float lbd, int normalize, int net, float* out, int nthreads);
+
+/* GTSRBNet (GTSRB/GTSRBNet.py:35-52).  tensors = 20 pointers in state_dict order
+ * (conv1_1.weight, conv1_1.bias, ... fc7_1.weight, fc7_1.bias), PyTorch layouts. */
+int or_gtsrb_forward(const float* const* tensors, const float* x, int N, float* logits, int nthreads);
+
+/* WideResNet (cifar/wideresnet.py:86-94).  tensors in the order documented in
+ * include/graphite_hip.h (gr_model_load_wrn). */
+int or_wrn_forward(const float* const* tensors, int ntensors, int depth, int widen, int num_classes,
+                   const float* x, int N, float* logits, int nthreads);
+
+/* torch.max(out,1) first-max argmax; hits[c] += (pred == target) over the T images of candidate c. */
+int or_argmax_hits(const float* logits, int N, int ncls, int T, int target, int64_t* preds, int32_t* hits);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
