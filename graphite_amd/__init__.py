@@ -1,0 +1,11 @@
+"""graphite_amd -- GRAPHITE's transform-robustness scoring path on MI355X (gfx950).
+
+Drop-in names (reference file:line in each module's docstring):
+    transforms.get_transform_params / get_transformed_images / add_noise / convert2Network /
+    apply_transformation, perspective_transform.get_perspective_transform,
+    utils.run_predictions, models.GTSRBNet / WideResNet (.predict), score.score_fn
+Added: `tr_hits` (fused, batched evaluation that never leaves the GPU).
+"""
+from .engine import tr_hits, tr_error_rates  # noqa: F401
+
+__all__ = ["tr_hits", "tr_error_rates"]

@@ -1,0 +1,290 @@
+"""ctypes binding of libgraphite_hip.so (include/graphite_hip.h).
+
+PyTorch-ROCm is used for device memory and streams only: every tensor handed to
+the library is a contiguous CUDA(ROCm) tensor whose `data_ptr()` crosses the C
+ABI together with `torch.cuda.current_stream().cuda_stream`.
+
+There is NO CPU fallback: if the shared library is missing, or no gfx950 device
+is visible, the first call raises.
+"""
+import ctypes as C
+import os
+import threading
+
+import numpy as np
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libgraphite_hip.so")
+
+XFORM_DTYPE = np.dtype([("M", np.float64, (9,)), ("crop_x", np.int32), ("crop_y", np.int32),
+                        ("blur", np.int32), ("pad_", np.int32), ("lut", np.uint8, (256,))], align=True)
+
+_vp, _i, _f, _i64 = C.c_void_p, C.c_int, C.c_float, C.c_int64
+
+# name -> (restype, argtypes); also the list checked by tests/test_abi.py against the header
+SIGNATURES = {
+    "gr_ctx_create": (_i, [_i, C.POINTER(_vp)]),
+    "gr_ctx_destroy": (None, [_vp]),
+    "gr_last_error": (C.c_char_p, [_vp]),
+    "gr_ctx_set_chunk": (_i, [_vp, _i]),
+    "gr_ctx_workspace_bytes": (_i64, [_vp]),
+    "gr_xforms_create": (_i, [_vp, _vp, _i, C.POINTER(_vp)]),
+    "gr_xforms_destroy": (None, [_vp]),
+    "gr_resize_linear": (_i, [_vp, _vp, _i, _i, _i, _vp, _i, _i, _vp]),
+    "gr_convert_to_network": (_i, [_vp, _vp, _i, _i, _vp, _i, _i, _vp]),
+    "gr_add_noise": (_i, [_vp, _vp, _i, _i, _vp, _vp, _i, _i, _f, _i, _vp, _vp, _vp, _vp]),
+    "gr_warp_perspective": (_i, [_vp, _vp, _i, _i, _vp, _i, _i, _vp, _vp]),
+    "gr_transform_composited": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp, _i, _i, _vp, _vp]),
+    "gr_warp_batch": (_i, [_vp, _vp, _i, _i, _vp, _vp, _i, _i, _i, _vp, _f, _i, _i, _vp, _vp]),
+    "gr_model_load_gtsrb": (_i, [_vp, _vp, _vp, _i, C.POINTER(_vp)]),
+    "gr_model_load_wrn": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, C.POINTER(_vp)]),
+    "gr_model_destroy": (None, [_vp]),
+    "gr_model_num_classes": (_i, [_vp]),
+    "gr_model_forward": (_i, [_vp, _vp, _vp, _i, _vp, _vp]),
+    "gr_model_predict": (_i, [_vp, _vp, _vp, _i, _vp, _vp]),
+    "gr_tr_hits": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp, _i, _i, _i, _vp, _f, _i, _i, _i64, _i64, _vp, _vp, _vp, _vp]),
+}
+
+_lib = None
+_lock = threading.Lock()
+_ctxs = {}
+
+
+class GraphiteHipError(RuntimeError):
+    pass
+
+
+def load_library():
+    """dlopen the in-tree library and declare every entry point.  Needs no GPU."""
+    global _lib
+    with _lock:
+        if _lib is None:
+            if not os.path.exists(LIB_PATH):
+                raise GraphiteHipError(
+                    f"{LIB_PATH} not found: build it with `make -C graphite_amd/csrc` "
+                    "(or __graft_entry__.build()); there is no CPU fallback")
+            lib = C.CDLL(LIB_PATH)
+            for name, (res, args) in SIGNATURES.items():
+                fn = getattr(lib, name)
+                fn.restype, fn.argtypes = res, args
+            _lib = lib
+    return _lib
+
+
+def _check(ctx, rc, what):
+    if rc != 0:
+        msg = load_library().gr_last_error(ctx)
+        raise GraphiteHipError(f"{what} failed ({rc}): {msg.decode() if msg else '?'}")
+
+
+def device_index():
+    if not torch.cuda.is_available():
+        raise GraphiteHipError("no ROCm device visible to PyTorch; graphite_amd has no CPU path")
+    return torch.cuda.current_device()
+
+
+def ctx():
+    """One gr_ctx per device, created on first use."""
+    lib = load_library()
+    dev = device_index()
+    with _lock:
+        c = _ctxs.get(dev)
+        if c is None:
+            h = _vp()
+            rc = lib.gr_ctx_create(dev, C.byref(h))
+            if rc != 0:
+                raise GraphiteHipError(f"gr_ctx_create({dev}) failed ({rc}): {lib.gr_last_error(None).decode()}")
+            c = _ctxs[dev] = h
+    return c
+
+
+def set_chunk(images_per_chunk):
+    _check(ctx(), load_library().gr_ctx_set_chunk(ctx(), int(images_per_chunk)), "gr_ctx_set_chunk")
+
+
+def workspace_bytes():
+    return int(load_library().gr_ctx_workspace_bytes(ctx()))
+
+
+def _stream():
+    return _vp(torch.cuda.current_stream().cuda_stream)
+
+
+def to_dev(a):
+    """float32 contiguous CUDA tensor from numpy / CPU tensor / CUDA tensor."""
+    if isinstance(a, np.ndarray):
+        a = torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32))
+    return a.to(device=f"cuda:{device_index()}", dtype=torch.float32).contiguous()
+
+
+def _p(t):
+    return _vp(t.data_ptr()) if t is not None else None
+
+
+class XformTable:
+    """Device copy of a transform table (gr_xforms)."""
+
+    def __init__(self, tab):
+        tab = np.ascontiguousarray(tab, dtype=XFORM_DTYPE)
+        self.T = int(tab.shape[0])
+        self.host = tab
+        self._h = _vp()
+        self._ctx = ctx()
+        _check(self._ctx, load_library().gr_xforms_create(self._ctx, tab.ctypes.data_as(_vp), self.T, C.byref(self._h)),
+               "gr_xforms_create")
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h and _lib is not None:
+            _lib.gr_xforms_destroy(h)
+
+
+_xf_cache = {}
+
+
+def xform_table(tab):
+    """Cached XformTable: an attack evaluates ~1,700 candidates against one transform list."""
+    if isinstance(tab, XformTable):
+        return tab
+    tab = np.ascontiguousarray(tab, dtype=XFORM_DTYPE)
+    key = (device_index(), hash(tab.tobytes()))
+    x = _xf_cache.get(key)
+    if x is None:
+        if len(_xf_cache) > 16:
+            _xf_cache.clear()
+        x = _xf_cache[key] = XformTable(tab)
+    return x
+
+
+# ------------------------------------------------------------------------------------------------
+# pixel operators (numpy in, numpy out -- the reference's functions take and return CPU data)
+# ------------------------------------------------------------------------------------------------
+def resize_linear(src, dh, dw):
+    s = to_dev(src)
+    c, sh, sw = s.shape
+    d = torch.empty((c, dh, dw), device=s.device, dtype=torch.float32)
+    _check(ctx(), load_library().gr_resize_linear(ctx(), _p(s), c, sh, sw, _p(d), dh, dw, _stream()), "gr_resize_linear")
+    return d.cpu().numpy()
+
+
+def convert_to_network(src, net, normalize):
+    s = to_dev(src)
+    _, sh, sw = s.shape
+    d = torch.empty((3, net, net), device=s.device, dtype=torch.float32)
+    _check(ctx(), load_library().gr_convert_to_network(ctx(), _p(s), sh, sw, _p(d), net, int(normalize), _stream()),
+           "gr_convert_to_network")
+    return d.cpu().numpy()
+
+
+def add_noise(img, mask, theta, lbd, clip):
+    i, m, t = to_dev(img), to_dev(mask), to_dev(theta)
+    _, H, W = i.shape
+    _, nh, nw = m.shape
+    comb, pert, ml = torch.empty_like(i), torch.empty_like(i), torch.empty_like(i)
+    _check(ctx(), load_library().gr_add_noise(ctx(), _p(i), H, W, _p(m), _p(t), nh, nw, lbd, int(clip), _p(comb), _p(pert),
+                                              _p(ml), _stream()), "gr_add_noise")
+    return comb.cpu().numpy(), pert.cpu().numpy(), ml.cpu().numpy()
+
+
+def warp_perspective_hwc(img_hwc, M, crop_x, crop_y):
+    s = to_dev(np.ascontiguousarray(np.transpose(img_hwc, (2, 0, 1))))
+    _, H, W = s.shape
+    Mh = np.ascontiguousarray(M, dtype=np.float64).reshape(9)
+    d = torch.empty((3, crop_y, crop_x), device=s.device, dtype=torch.float32)
+    _check(ctx(), load_library().gr_warp_perspective(ctx(), _p(s), H, W, Mh.ctypes.data_as(_vp), crop_x, crop_y, _p(d),
+                                                     _stream()), "gr_warp_perspective")
+    return np.ascontiguousarray(np.transpose(d.cpu().numpy(), (1, 2, 0)))
+
+
+def transform_composited(img, mask_lg, pert, tab, net, normalize):
+    i, m, p = to_dev(img), to_dev(mask_lg), to_dev(pert)
+    _, H, W = i.shape
+    xf = xform_table(tab)
+    out = torch.empty((xf.T, 3, net, net), device=i.device, dtype=torch.float32)
+    _check(ctx(), load_library().gr_transform_composited(ctx(), _p(i), _p(m), _p(p), H, W, xf._h, int(normalize), net,
+                                                         _p(out), _stream()), "gr_transform_composited")
+    return out.cpu().numpy()
+
+
+def warp_batch_dev(img, masks, thetas, tab, lbd, normalize, net=32):
+    """Device-resident get_transformed_images for C candidates: returns a CUDA tensor [C,T,3,net,net]."""
+    i, m, t = to_dev(img), to_dev(masks), to_dev(thetas)
+    _, H, W = i.shape
+    Cn, _, nh, nw = m.shape
+    assert t.shape == m.shape
+    xf = xform_table(tab)
+    out = torch.empty((Cn, xf.T, 3, net, net), device=i.device, dtype=torch.float32)
+    _check(ctx(), load_library().gr_warp_batch(ctx(), _p(i), H, W, _p(m), _p(t), Cn, nh, nw, xf._h, lbd, int(normalize), net,
+                                               _p(out), _stream()), "gr_warp_batch")
+    return out
+
+
+def warp_batch(img, masks, thetas, tab, lbd, normalize, net=32):
+    return warp_batch_dev(img, masks, thetas, tab, lbd, normalize, net).cpu().numpy()
+
+
+# ------------------------------------------------------------------------------------------------
+# classifiers
+# ------------------------------------------------------------------------------------------------
+class Model:
+    """gr_model handle.  `kind` = 'gtsrb' (20 tensors) or 'wrn' (see weights.wrn_tensor_list)."""
+
+    def __init__(self, kind, tensors, depth=34, widen=10, num_classes=10):
+        lib = load_library()
+        self._ctx = ctx()
+        keep = [np.ascontiguousarray(t, dtype=np.float32) for t in tensors]
+        ptrs = (_vp * len(keep))(*[t.ctypes.data for t in keep])
+        numel = (C.c_int64 * len(keep))(*[t.size for t in keep])
+        self._h = _vp()
+        self.kind = kind
+        if kind == "gtsrb":
+            rc = lib.gr_model_load_gtsrb(self._ctx, ptrs, numel, len(keep), C.byref(self._h))
+        elif kind == "wrn":
+            rc = lib.gr_model_load_wrn(self._ctx, ptrs, numel, len(keep), depth, widen, num_classes, C.byref(self._h))
+        else:
+            raise ValueError(kind)
+        _check(self._ctx, rc, f"gr_model_load_{kind}")
+        self.num_classes = int(lib.gr_model_num_classes(self._h))
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h and _lib is not None:
+            _lib.gr_model_destroy(h)
+
+    def forward(self, x):
+        """x: [N,3,32,32] (any device) -> logits CUDA tensor [N,ncls]."""
+        xd = to_dev(x)
+        n = xd.shape[0]
+        out = torch.empty((n, self.num_classes), device=xd.device, dtype=torch.float32)
+        _check(self._ctx, load_library().gr_model_forward(self._ctx, self._h, _p(xd), n, _p(out), _stream()),
+               "gr_model_forward")
+        return out
+
+    def predict_dev(self, x):
+        xd = to_dev(x)
+        n = xd.shape[0]
+        out = torch.empty((n,), device=xd.device, dtype=torch.int64)
+        _check(self._ctx, load_library().gr_model_predict(self._ctx, self._h, _p(xd), n, _p(out), _stream()),
+               "gr_model_predict")
+        return out
+
+
+def tr_hits_dev(model, img, masks, thetas, tab, lbd, normalize, target, img_begin=0, img_count=None,
+                want_preds=False, want_logits=False):
+    """Fused TR evaluation; everything stays on the GPU.  Returns (hits int32[C] CUDA, preds|None, logits|None)."""
+    i, m, t = to_dev(img), to_dev(masks), to_dev(thetas)
+    _, H, W = i.shape
+    Cn, _, nh, nw = m.shape
+    assert t.shape == m.shape
+    xf = xform_table(tab)
+    total = Cn * xf.T
+    if img_count is None:
+        img_count = total - img_begin
+    hits = torch.empty((Cn,), device=i.device, dtype=torch.int32)
+    preds = torch.full((total,), -1, device=i.device, dtype=torch.int64) if want_preds else None
+    logits = torch.zeros((total, model.num_classes), device=i.device, dtype=torch.float32) if want_logits else None
+    _check(model._ctx, load_library().gr_tr_hits(model._ctx, model._h, _p(i), H, W, _p(m), _p(t), Cn, nh, nw, xf._h, lbd,
+                                                 int(normalize), int(target), int(img_begin), int(img_count), _p(hits),
+                                                 _p(preds), _p(logits), _stream()), "gr_tr_hits")
+    return hits, preds, logits

@@ -1,0 +1,308 @@
+// api.hip -- the extern "C" surface of libgraphite_hip.so (see include/graphite_hip.h).
+#include "common.h"
+#include <limits.h>
+#include <stdarg.h>
+#include <string.h>
+
+static thread_local std::string g_create_err;
+
+int gr_fail(gr_ctx* ctx, int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    if (ctx) ctx->err = buf; else g_create_err = buf;
+    return code;
+}
+
+// Grow-only device workspace.  Growing synchronises the device (frees the old block).
+int gr_ws_reserve(gr_ctx* ctx, size_t bytes, void* stream) {
+    (void)stream;
+    if (bytes <= ctx->ws_bytes) return GR_OK;
+    if (ctx->ws) {
+        GR_HIP(ctx, hipDeviceSynchronize());
+        GR_HIP(ctx, hipFree(ctx->ws));
+        ctx->ws = nullptr;
+        ctx->ws_bytes = 0;
+    }
+    size_t want = gr_align(bytes + bytes / 8, 1 << 20);
+    hipError_t e = hipMalloc((void**)&ctx->ws, want);
+    if (e != hipSuccess) {
+        ctx->ws = nullptr;
+        return gr_fail(ctx, GR_ENOMEM, "workspace hipMalloc(%zu) failed: %s", want, hipGetErrorString(e));
+    }
+    ctx->ws_bytes = want;
+    return GR_OK;
+}
+
+extern "C" int gr_ctx_create(int device, gr_ctx** out) {
+    if (!out) return gr_fail(nullptr, GR_EINVAL, "gr_ctx_create: out is null");
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) return gr_fail(nullptr, GR_EHIP, "no HIP device: %s", hipGetErrorString(e));
+    if (device < 0 || device >= n) return gr_fail(nullptr, GR_EINVAL, "device %d out of range (0..%d)", device, n - 1);
+    e = hipSetDevice(device);
+    if (e != hipSuccess) return gr_fail(nullptr, GR_EHIP, "hipSetDevice: %s", hipGetErrorString(e));
+    hipDeviceProp_t prop;
+    e = hipGetDeviceProperties(&prop, device);
+    if (e != hipSuccess) return gr_fail(nullptr, GR_EHIP, "hipGetDeviceProperties: %s", hipGetErrorString(e));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return gr_fail(nullptr, GR_ESTATE, "device %d is %s; this library is built for gfx950 only", device, prop.gcnArchName);
+    gr_ctx* c = new gr_ctx();
+    c->device = device;
+    *out = c;
+    return GR_OK;
+}
+
+extern "C" void gr_ctx_destroy(gr_ctx* ctx) {
+    if (!ctx) return;
+    if (ctx->ws) { (void)hipDeviceSynchronize(); (void)hipFree(ctx->ws); }
+    delete ctx;
+}
+
+extern "C" const char* gr_last_error(const gr_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_err.c_str(); }
+
+extern "C" int gr_ctx_set_chunk(gr_ctx* ctx, int n) {
+    if (!ctx) return GR_EINVAL;
+    if (n < 64 || n > (1 << 20)) return gr_fail(ctx, GR_EINVAL, "chunk must be in [64, 1048576]");
+    ctx->chunk = n;
+    return GR_OK;
+}
+extern "C" int64_t gr_ctx_workspace_bytes(const gr_ctx* ctx) { return ctx ? (int64_t)ctx->ws_bytes : 0; }
+
+// ---------------------------------------------------------------------------------------------
+// transform table
+// ---------------------------------------------------------------------------------------------
+// cv::invert for a 3x3 CV_64F matrix (closed-form adjugate; what cv::warpPerspective applies to M)
+static void invert3x3(const double* S, double* t) {
+    double det = S[0] * (S[4] * S[8] - S[5] * S[7]) - S[1] * (S[3] * S[8] - S[5] * S[6]) + S[2] * (S[3] * S[7] - S[4] * S[6]);
+    if (det == 0.0) { memset(t, 0, 9 * sizeof(double)); return; }
+    double d = 1.0 / det;
+    t[0] = (S[4] * S[8] - S[5] * S[7]) * d;
+    t[1] = (S[2] * S[7] - S[1] * S[8]) * d;
+    t[2] = (S[1] * S[5] - S[2] * S[4]) * d;
+    t[3] = (S[5] * S[6] - S[3] * S[8]) * d;
+    t[4] = (S[0] * S[8] - S[2] * S[6]) * d;
+    t[5] = (S[2] * S[3] - S[0] * S[5]) * d;
+    t[6] = (S[3] * S[7] - S[4] * S[6]) * d;
+    t[7] = (S[1] * S[6] - S[0] * S[7]) * d;
+    t[8] = (S[0] * S[4] - S[1] * S[3]) * d;
+}
+static int warp_block_w(int width, int height) {     // column-block width of cv::WarpPerspectiveInvoker
+    int bh0 = 16 < height ? 16 : height;
+    int bw0 = 1024 / bh0;
+    return bw0 > width ? width : bw0;
+}
+
+extern "C" int gr_xforms_create(gr_ctx* ctx, const gr_xform* h, int T, gr_xforms** out) {
+    if (!ctx) return GR_EINVAL;
+    if (!h || !out || T <= 0) return gr_fail(ctx, GR_EINVAL, "gr_xforms_create: bad arguments");
+    GR_HIP(ctx, hipSetDevice(ctx->device));
+    int slot_of[8];
+    for (int i = 0; i < 8; i++) slot_of[i] = -1;
+    gr_xforms* x = new gr_xforms();
+    x->ctx = ctx; x->T = T;
+    std::vector<XformDev> d(T);
+    for (int b = 0; b <= 7; b++) {                   // slots in ascending kernel size
+        bool used = false;
+        for (int t = 0; t < T && !used; t++) used = h[t].blur == b;
+        if (used) {
+            if (!(b == 0 || b == 3 || b == 5 || b == 7)) { delete x; return gr_fail(ctx, GR_EINVAL, "unsupported blur kernel %d", b); }
+            x->slot_blur[x->nslots] = b;
+            slot_of[b] = x->nslots++;
+        }
+    }
+    for (int t = 0; t < T; t++) {
+        if (h[t].blur < 0 || h[t].blur > 7 || slot_of[h[t].blur] < 0) { delete x; return gr_fail(ctx, GR_EINVAL, "unsupported blur kernel %d", h[t].blur); }
+        if (h[t].crop_x <= 0 || h[t].crop_y <= 0 || h[t].crop_x > 16384 || h[t].crop_y > 16384) {
+            delete x;
+            return gr_fail(ctx, GR_EINVAL, "transform %d: bad crop %dx%d", t, h[t].crop_x, h[t].crop_y);
+        }
+        invert3x3(h[t].M, d[t].Mi);
+        d[t].crop_x = h[t].crop_x; d[t].crop_y = h[t].crop_y;
+        d[t].slot = slot_of[h[t].blur];
+        d[t].bw0 = warp_block_w(h[t].crop_x, h[t].crop_y);
+        memcpy(d[t].lut, h[t].lut, 256);
+    }
+    hipError_t e = hipMalloc((void**)&x->dev, sizeof(XformDev) * T);
+    if (e != hipSuccess) { delete x; return gr_fail(ctx, GR_ENOMEM, "xforms hipMalloc: %s", hipGetErrorString(e)); }
+    e = hipMemcpy(x->dev, d.data(), sizeof(XformDev) * T, hipMemcpyHostToDevice);
+    if (e != hipSuccess) { (void)hipFree(x->dev); delete x; return gr_fail(ctx, GR_EHIP, "xforms upload: %s", hipGetErrorString(e)); }
+    *out = x;
+    return GR_OK;
+}
+extern "C" void gr_xforms_destroy(gr_xforms* x) {
+    if (!x) return;
+    if (x->dev) (void)hipFree(x->dev);
+    delete x;
+}
+
+// ---------------------------------------------------------------------------------------------
+// pixel operators
+// ---------------------------------------------------------------------------------------------
+#define NEED_CTX() do { if (!ctx) return GR_EINVAL; } while (0)
+
+extern "C" int gr_resize_linear(gr_ctx* ctx, const float* src, int C, int sh, int sw, float* dst, int dh, int dw, void* stream) {
+    NEED_CTX();
+    if (!src || !dst || C <= 0 || sh <= 0 || sw <= 0 || dh <= 0 || dw <= 0) return gr_fail(ctx, GR_EINVAL, "gr_resize_linear: bad arguments");
+    return px_resize(ctx, src, C, sh, sw, dst, dh, dw, 0, 0, (hipStream_t)stream);
+}
+extern "C" int gr_convert_to_network(gr_ctx* ctx, const float* src, int sh, int sw, float* dst, int net, int normalize, void* stream) {
+    NEED_CTX();
+    if (!src || !dst || sh <= 0 || sw <= 0 || net <= 0) return gr_fail(ctx, GR_EINVAL, "gr_convert_to_network: bad arguments");
+    return px_resize(ctx, src, 3, sh, sw, dst, net, net, 1, normalize, (hipStream_t)stream);
+}
+extern "C" int gr_add_noise(gr_ctx* ctx, const float* img, int H, int W, const float* mask, const float* theta, int nh, int nw,
+                            float lbd, int clip, float* comb, float* pert, float* mask_lg, void* stream) {
+    NEED_CTX();
+    if (!img || !mask || !theta || H <= 0 || W <= 0 || nh <= 0 || nw <= 0) return gr_fail(ctx, GR_EINVAL, "gr_add_noise: bad arguments");
+    return px_add_noise(ctx, img, H, W, mask, theta, nh, nw, lbd, clip, comb, pert, mask_lg, (hipStream_t)stream);
+}
+extern "C" int gr_warp_perspective(gr_ctx* ctx, const float* src, int H, int W, const double* M, int crop_x, int crop_y,
+                                   float* dst, void* stream) {
+    NEED_CTX();
+    if (!src || !M || !dst || H <= 0 || W <= 0 || crop_x <= 0 || crop_y <= 0) return gr_fail(ctx, GR_EINVAL, "gr_warp_perspective: bad arguments");
+    double Mi[9];
+    invert3x3(M, Mi);
+    return px_warp_full(ctx, src, H, W, Mi, crop_x, crop_y, dst, (hipStream_t)stream);
+}
+
+static int check_frame(gr_ctx* ctx, int H, int W, int nh, int nw, int net, const gr_xforms* xf) {
+    if (!xf || xf->ctx != ctx) return gr_fail(ctx, GR_ESTATE, "transform table belongs to another context");
+    if (H <= 0 || W <= 0 || nh <= 0 || nw <= 0 || net <= 0 || net > 1024) return gr_fail(ctx, GR_EINVAL, "bad frame sizes");
+    if ((long long)H * W > (1 << 28)) return gr_fail(ctx, GR_EINVAL, "frame too large");
+    return GR_OK;
+}
+
+extern "C" int gr_transform_composited(gr_ctx* ctx, const float* img, const float* mask_lg, const float* pert, int H, int W,
+                                       const gr_xforms* xf, int normalize, int net, float* out, void* stream) {
+    NEED_CTX();
+    if (!img || !mask_lg || !pert || !out) return gr_fail(ctx, GR_EINVAL, "gr_transform_composited: null pointer");
+    int rc = check_frame(ctx, H, W, H, W, net, xf);
+    if (rc) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    size_t att_bytes = gr_align((size_t)xf->nslots * H * W * 16);
+    if ((rc = gr_ws_reserve(ctx, att_bytes, stream))) return rc;
+    float* att = (float*)ctx->ws;
+    if ((rc = px_composite_from_pert(ctx, img, mask_lg, pert, H, W, xf, att, st))) return rc;
+    return px_warp_net(ctx, att, H, W, xf, 0, xf->T, 0, normalize, net, out, st);
+}
+
+extern "C" int gr_warp_batch(gr_ctx* ctx, const float* img, int H, int W, const float* masks, const float* thetas, int C, int nh,
+                             int nw, const gr_xforms* xf, float lbd, int normalize, int net, float* out, void* stream) {
+    NEED_CTX();
+    if (!img || !masks || !thetas || !out || C < 0) return gr_fail(ctx, GR_EINVAL, "gr_warp_batch: bad arguments");
+    int rc = check_frame(ctx, H, W, nh, nw, net, xf);
+    if (rc) return rc;
+    if (C == 0) return GR_OK;
+    hipStream_t st = (hipStream_t)stream;
+    const size_t per_cand = (size_t)xf->nslots * H * W * 16;
+    // candidates per pass bounded by ~2 GiB of composites
+    int cpass = (int)(((size_t)2 << 30) / per_cand);
+    if (cpass < 1) cpass = 1;
+    if (cpass > C) cpass = C;
+    if ((rc = gr_ws_reserve(ctx, gr_align(per_cand * cpass), stream))) return rc;
+    float* att = (float*)ctx->ws;
+    const int T = xf->T;
+    for (int c0 = 0; c0 < C; c0 += cpass) {
+        int nc = C - c0 < cpass ? C - c0 : cpass;
+        if ((rc = px_composite(ctx, img, H, W, masks + (size_t)c0 * 3 * nh * nw, thetas + (size_t)c0 * 3 * nh * nw, nc, nh, nw,
+                               lbd, xf, att, st))) return rc;
+        long long nimg = (long long)nc * T;
+        for (long long o = 0; o < nimg; o += (1 << 30)) {
+            int cnt = (int)(nimg - o < (1 << 30) ? nimg - o : (1 << 30));
+            if ((rc = px_warp_net(ctx, att, H, W, xf, (int64_t)c0 * T + o, cnt, c0, normalize, net,
+                                  out + ((size_t)c0 * T + o) * 3 * net * net, st))) return rc;
+        }
+    }
+    return GR_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// classifiers
+// ---------------------------------------------------------------------------------------------
+extern "C" int gr_model_forward(gr_ctx* ctx, gr_model* m, const float* x, int N, float* logits, void* stream) {
+    NEED_CTX();
+    if (!m || !x || !logits || N < 0) return gr_fail(ctx, GR_EINVAL, "gr_model_forward: bad arguments");
+    hipStream_t st = (hipStream_t)stream;
+    const int ncls = gr_model_num_classes(m);
+    int chunk = ctx->chunk < N ? ctx->chunk : N;
+    if (chunk <= 0) return GR_OK;
+    size_t wsb = net_workspace_bytes(m, chunk);
+    int rc = gr_ws_reserve(ctx, wsb, stream);
+    if (rc) return rc;
+    for (int n0 = 0; n0 < N; n0 += chunk) {
+        int nb = N - n0 < chunk ? N - n0 : chunk;
+        if ((rc = net_forward(ctx, m, x + (size_t)n0 * 3072, nb, logits + (size_t)n0 * ncls, ctx->ws, ctx->ws_bytes, st))) return rc;
+    }
+    return GR_OK;
+}
+
+extern "C" int gr_model_predict(gr_ctx* ctx, gr_model* m, const float* x, int N, int64_t* preds, void* stream) {
+    NEED_CTX();
+    if (!m || !x || !preds || N < 0) return gr_fail(ctx, GR_EINVAL, "gr_model_predict: bad arguments");
+    hipStream_t st = (hipStream_t)stream;
+    const int ncls = gr_model_num_classes(m);
+    int chunk = ctx->chunk < N ? ctx->chunk : N;
+    if (chunk <= 0) return GR_OK;
+    size_t lg_bytes = gr_align((size_t)chunk * ncls * sizeof(float));
+    size_t wsb = net_workspace_bytes(m, chunk);
+    int rc = gr_ws_reserve(ctx, lg_bytes + wsb, stream);
+    if (rc) return rc;
+    float* lg = (float*)ctx->ws;
+    for (int n0 = 0; n0 < N; n0 += chunk) {
+        int nb = N - n0 < chunk ? N - n0 : chunk;
+        if ((rc = net_forward(ctx, m, x + (size_t)n0 * 3072, nb, lg, ctx->ws + lg_bytes, ctx->ws_bytes - lg_bytes, st))) return rc;
+        if ((rc = net_argmax(ctx, lg, nb, ncls, preds + n0, st))) return rc;
+    }
+    return GR_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// fused TR evaluation
+// ---------------------------------------------------------------------------------------------
+extern "C" int gr_tr_hits(gr_ctx* ctx, gr_model* m, const float* img, int H, int W, const float* masks, const float* thetas,
+                          int C, int nh, int nw, const gr_xforms* xf, float lbd, int normalize, int target, int64_t img_begin,
+                          int64_t img_count, int32_t* hits, int64_t* preds, float* logits, void* stream) {
+    NEED_CTX();
+    if (!m || !img || !masks || !thetas || !hits || C < 0) return gr_fail(ctx, GR_EINVAL, "gr_tr_hits: bad arguments");
+    int rc = check_frame(ctx, H, W, nh, nw, 32, xf);
+    if (rc) return rc;
+    const int T = xf->T;
+    const int64_t total = (int64_t)C * T;
+    if (img_begin < 0 || img_count < 0 || img_begin + img_count > total) return gr_fail(ctx, GR_EINVAL, "gr_tr_hits: image slice out of range");
+    hipStream_t st = (hipStream_t)stream;
+    if (C > 0) GR_HIP(ctx, hipMemsetAsync(hits, 0, sizeof(int32_t) * C, st));
+    if (img_count == 0) return GR_OK;
+    const int ncls = gr_model_num_classes(m);
+    const int chunk = (int)(ctx->chunk < img_count ? ctx->chunk : img_count);
+    // workspace: composites of the candidates one chunk can touch | chunk images CHW | chunk logits | net scratch
+    const int max_cand = (int)((chunk + T - 1) / T + 1);
+    const size_t per_cand = (size_t)xf->nslots * H * W * 16;
+    const size_t att_bytes = gr_align(per_cand * (size_t)(max_cand < C ? max_cand : C));
+    const size_t x_bytes = gr_align((size_t)chunk * 3072 * sizeof(float));
+    const size_t lg_bytes = gr_align((size_t)chunk * ncls * sizeof(float));
+    const size_t net_bytes = net_workspace_bytes(m, chunk);
+    if ((rc = gr_ws_reserve(ctx, att_bytes + x_bytes + lg_bytes + net_bytes, stream))) return rc;
+    float* att = (float*)ctx->ws;
+    float* xb = (float*)(ctx->ws + att_bytes);
+    float* lg = (float*)(ctx->ws + att_bytes + x_bytes);
+    char* nws = ctx->ws + att_bytes + x_bytes + lg_bytes;
+    int have_lo = -1, have_hi = -1;     // candidates whose composites are currently in `att`
+    for (int64_t n0 = img_begin; n0 < img_begin + img_count; n0 += chunk) {
+        int nb = (int)(img_begin + img_count - n0 < chunk ? img_begin + img_count - n0 : chunk);
+        int c_lo = (int)(n0 / T), c_hi = (int)((n0 + nb - 1) / T);
+        if (!(c_lo >= have_lo && c_hi <= have_hi)) {
+            int nc = c_hi - c_lo + 1;
+            if ((rc = px_composite(ctx, img, H, W, masks + (size_t)c_lo * 3 * nh * nw, thetas + (size_t)c_lo * 3 * nh * nw, nc,
+                                   nh, nw, lbd, xf, att, st))) return rc;
+            have_lo = c_lo; have_hi = c_hi;
+        }
+        if ((rc = px_warp_net(ctx, att, H, W, xf, n0, nb, have_lo, normalize, 32, xb, st))) return rc;
+        float* lg_out = logits ? logits + (size_t)n0 * ncls : lg;
+        if ((rc = net_forward(ctx, m, xb, nb, lg_out, nws, net_bytes, st))) return rc;
+        if ((rc = net_hits(ctx, lg_out, nb, ncls, n0, T, target, hits, preds ? preds + n0 : nullptr, st))) return rc;
+    }
+    return GR_OK;
+}

@@ -1,0 +1,70 @@
+// Internal definitions shared by the translation units of libgraphite_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string>
+#include <vector>
+#include "graphite_hip.h"
+
+struct gr_ctx {
+    int device = 0;
+    std::string err;
+    char* ws = nullptr;          // device workspace, grown on demand
+    size_t ws_bytes = 0;
+    int chunk = 8192;            // images per classifier chunk in gr_tr_hits
+};
+
+// Device-side transform descriptor: inverse matrix (double), crop, blur slot, block width of the
+// cv::warpPerspective tiling (coordinates are computed relative to the block start), gamma LUT.
+struct XformDev {
+    double Mi[9];
+    int32_t crop_x, crop_y;
+    int32_t slot;                // index of the composite (blur variant) this transform samples
+    int32_t bw0;
+    uint8_t lut[256];
+};
+
+struct gr_xforms {
+    gr_ctx* ctx = nullptr;
+    int T = 0;
+    XformDev* dev = nullptr;
+    int nslots = 0;              // number of distinct blur kernels in the table
+    int slot_blur[4] = {0, 0, 0, 0};   // blur kernel size of each slot
+};
+
+int gr_fail(gr_ctx* ctx, int code, const char* fmt, ...);
+int gr_ws_reserve(gr_ctx* ctx, size_t bytes, void* stream);
+
+#define GR_HIP(ctx, call)                                                                          \
+    do {                                                                                           \
+        hipError_t e_ = (call);                                                                    \
+        if (e_ != hipSuccess) return gr_fail(ctx, GR_EHIP, "%s: %s", #call, hipGetErrorString(e_)); \
+    } while (0)
+
+static inline size_t gr_align(size_t v, size_t a = 256) { return (v + a - 1) / a * a; }
+
+// ---- pixel.hip (launchers used by api.hip) ----
+int px_resize(gr_ctx*, const float* src, int C, int sh, int sw, float* dst, int dh, int dw, int clamp, int normalize,
+              hipStream_t);
+int px_add_noise(gr_ctx*, const float* img, int H, int W, const float* mask, const float* theta, int nh, int nw,
+                 float lbd, int clip, float* comb, float* pert, float* mask_lg, hipStream_t);
+int px_warp_full(gr_ctx*, const float* src, int H, int W, const double* Mi, int crop_x, int crop_y, float* dst,
+                 hipStream_t);
+// composites for `ncand` candidates: att = [ncand][nslots][H][W][4] f32 (RGBX)
+int px_composite(gr_ctx*, const float* img, int H, int W, const float* masks, const float* thetas, int ncand, int nh,
+                 int nw, float lbd, const gr_xforms* xf, float* att, hipStream_t);
+int px_composite_from_pert(gr_ctx*, const float* img, const float* mask_lg, const float* pert, int H, int W,
+                           const gr_xforms* xf, float* att, hipStream_t);
+// images n in [n_begin, n_begin+count): candidate n/T (composite index n/T - cand0), transform n%T.
+// out_chw != null: [count,3,net,net] CHW f32.
+int px_warp_net(gr_ctx*, const float* att, int H, int W, const gr_xforms* xf, int64_t n_begin, int count, int cand0,
+                int normalize, int net, float* out_chw, hipStream_t);
+
+// ---- nets.hip ----
+struct gr_model;
+int net_forward(gr_ctx*, gr_model*, const float* x_chw, int N, float* logits, char* ws, size_t ws_bytes, hipStream_t);
+size_t net_workspace_bytes(const gr_model*, int N);
+int net_argmax(gr_ctx*, const float* logits, int N, int ncls, int64_t* preds, hipStream_t);
+int net_hits(gr_ctx*, const float* logits, int N, int ncls, int64_t n_begin, int T, int target, int32_t* hits,
+             int64_t* preds, hipStream_t);

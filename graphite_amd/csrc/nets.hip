@@ -1,0 +1,410 @@
+// nets.hip -- victim classifiers of the transform-robustness path on gfx950:
+//   GTSRBNet        (reference GTSRB/GTSRBNet.py:8-52)
+//   WideResNet-d-w  (reference cifar/wideresnet.py:9-94; 34-10 in the paper's CIFAR attack)
+// Every conv / linear layer runs on the fp32 matrix cores through conv_igemm.h; the argmax +
+// target-hit count is a wavefront-reduction kernel (utils.py:51-52).
+#include "common.h"
+#include "conv_igemm.h"
+#include <math.h>
+#include <stdarg.h>
+#include <string.h>
+
+// ---------------------------------------------------------------------------------------------
+// model objects
+// ---------------------------------------------------------------------------------------------
+struct Layer {
+    float* w = nullptr;      // [K][NP]
+    float* bias = nullptr;   // [NP]
+    int Cin = 0, Cout = 0, NP = 0, KH = 1, KW = 1, stride = 1, pad = 0;
+};
+struct BnDev { float* scale = nullptr; float* shift = nullptr; };
+struct WrnBlock {
+    int cin, cout, stride;
+    BnDev bn1, bn2;
+    Layer conv1, conv2, sc;
+    bool has_sc;
+};
+struct gr_model {
+    gr_ctx* ctx = nullptr;
+    int kind = 0;            // 1 = GTSRBNet, 2 = WideResNet
+    int ncls = 0;
+    std::vector<void*> allocs;
+    // GTSRBNet
+    float* c11 = nullptr;    // conv1_1: 9 weights + 3 biases
+    Layer g[9];              // conv2_1 .. fc7_1
+    // WideResNet
+    Layer wconv1, wfc;
+    std::vector<WrnBlock> blocks;
+    BnDev bnf;
+    int ch[4] = {0, 0, 0, 0};
+};
+
+static int n_tile(int cout) {   // N tile the dispatcher will use for this many output channels
+    if (cout % 160 == 0) return 160;
+    if (cout >= 128) return 128;
+    if (cout >= 64) return 64;
+    return 32;
+}
+
+static int upload(gr_model* m, const std::vector<float>& h, float** d) {
+    GR_HIP(m->ctx, hipMalloc((void**)d, h.size() * sizeof(float)));
+    m->allocs.push_back(*d);
+    GR_HIP(m->ctx, hipMemcpy(*d, h.data(), h.size() * sizeof(float), hipMemcpyHostToDevice));
+    return GR_OK;
+}
+
+// OIHW -> [k = (ky*KW+kx)*CinP + ci][NP], zero padded in ci (CinP) and co (NP)
+static int make_layer(gr_model* m, Layer* L, const float* w, const float* bias, int Co, int Ci, int KH, int KW, int stride,
+                      int pad) {
+    int CinP = (Ci + 3) / 4 * 4;
+    int bn = n_tile(Co);
+    int NP = (Co + bn - 1) / bn * bn;
+    std::vector<float> p((size_t)KH * KW * CinP * NP, 0.f);
+    for (int o = 0; o < Co; o++)
+        for (int i = 0; i < Ci; i++)
+            for (int y = 0; y < KH; y++)
+                for (int x = 0; x < KW; x++)
+                    p[((size_t)(y * KW + x) * CinP + i) * NP + o] = w[(((size_t)o * Ci + i) * KH + y) * KW + x];
+    int rc = upload(m, p, &L->w);
+    if (rc) return rc;
+    if (bias) {
+        std::vector<float> b(NP, 0.f);
+        memcpy(b.data(), bias, sizeof(float) * Co);
+        rc = upload(m, b, &L->bias);
+        if (rc) return rc;
+    }
+    L->Cin = CinP; L->Cout = Co; L->NP = NP; L->KH = KH; L->KW = KW; L->stride = stride; L->pad = pad;
+    return GR_OK;
+}
+
+// eval BatchNorm folded as PyTorch's CPU kernel does: alpha = w/sqrt(var+eps), beta = b - mean*alpha
+static int make_bn(gr_model* m, BnDev* bn, const float* w, const float* b, const float* mean, const float* var, int C) {
+    int NP = (C + n_tile(C) - 1) / n_tile(C) * n_tile(C);
+    std::vector<float> sc(NP, 0.f), sh(NP, 0.f);
+    for (int c = 0; c < C; c++) {
+        float invstd = 1.0f / sqrtf(var[c] + 1e-5f);
+        sc[c] = w[c] * invstd;
+        sh[c] = b[c] - mean[c] * sc[c];
+    }
+    int rc = upload(m, sc, &bn->scale);
+    if (rc) return rc;
+    return upload(m, sh, &bn->shift);
+}
+
+static int expect(gr_ctx* ctx, const int64_t* numel, int idx, int64_t want) {
+    if (numel[idx] != want) return gr_fail(ctx, GR_EINVAL, "tensor %d has %lld elements, expected %lld", idx,
+                                           (long long)numel[idx], (long long)want);
+    return GR_OK;
+}
+
+extern "C" int gr_model_load_gtsrb(gr_ctx* ctx, const float* const* t, const int64_t* numel, int n, gr_model** out) {
+    if (!ctx) return GR_EINVAL;
+    if (!t || !numel || !out || n != 20) return gr_fail(ctx, GR_EINVAL, "gr_model_load_gtsrb: need 20 tensors");
+    GR_HIP(ctx, hipSetDevice(ctx->device));
+    static const int co[10] = {3, 32, 32, 64, 64, 128, 128, 1024, 1024, 43};
+    static const int ci[10] = {3, 3, 32, 32, 64, 64, 128, 2048, 1024, 1024};
+    static const int ks[10] = {1, 5, 5, 5, 5, 5, 5, 1, 1, 1};
+    for (int l = 0; l < 10; l++) {
+        int rc = expect(ctx, numel, 2 * l, (int64_t)co[l] * ci[l] * ks[l] * ks[l]);
+        if (rc) return rc;
+        rc = expect(ctx, numel, 2 * l + 1, co[l]);
+        if (rc) return rc;
+        if (!t[2 * l] || !t[2 * l + 1]) return gr_fail(ctx, GR_EINVAL, "null tensor %d", 2 * l);
+    }
+    gr_model* m = new gr_model();
+    m->ctx = ctx; m->kind = 1; m->ncls = 43;
+    int rc;
+    {
+        std::vector<float> c(12);
+        memcpy(c.data(), t[0], 9 * sizeof(float));
+        memcpy(c.data() + 9, t[1], 3 * sizeof(float));
+        rc = upload(m, c, &m->c11);
+    }
+    for (int l = 1; l <= 6 && !rc; l++) rc = make_layer(m, &m->g[l - 1], t[2 * l], t[2 * l + 1], co[l], ci[l], 5, 5, 1, 2);
+    if (!rc) {
+        // fc5_1: the reference flattens NCHW (k = c*16 + y*4 + x, GTSRBNet.py:47); activations here are
+        // NHWC, so the columns are permuted to k' = (y*4+x)*128 + c.
+        std::vector<float> w5((size_t)1024 * 2048);
+        for (int o = 0; o < 1024; o++)
+            for (int c = 0; c < 128; c++)
+                for (int s = 0; s < 16; s++) w5[(size_t)o * 2048 + s * 128 + c] = t[14][(size_t)o * 2048 + c * 16 + s];
+        rc = make_layer(m, &m->g[6], w5.data(), t[15], 1024, 2048, 1, 1, 1, 0);
+    }
+    if (!rc) rc = make_layer(m, &m->g[7], t[16], t[17], 1024, 1024, 1, 1, 1, 0);
+    if (!rc) rc = make_layer(m, &m->g[8], t[18], t[19], 43, 1024, 1, 1, 1, 0);
+    if (rc) { gr_model_destroy(m); return rc; }
+    *out = m;
+    return GR_OK;
+}
+
+extern "C" int gr_model_load_wrn(gr_ctx* ctx, const float* const* t, const int64_t* numel, int n, int depth, int widen,
+                                 int ncls, gr_model** out) {
+    if (!ctx) return GR_EINVAL;
+    if (!t || !numel || !out || depth < 10 || (depth - 4) % 6 != 0 || widen < 1 || ncls < 1 || ncls > 32)
+        return gr_fail(ctx, GR_EINVAL, "gr_model_load_wrn: bad arguments");
+    GR_HIP(ctx, hipSetDevice(ctx->device));
+    int nb = (depth - 4) / 6;
+    int ch[4] = {16, 16 * widen, 32 * widen, 64 * widen};
+    // count + size check first
+    int want = 1;
+    for (int g = 0; g < 3; g++)
+        for (int i = 0; i < nb; i++) want += 10 + (((i == 0 ? ch[g] : ch[g + 1]) != ch[g + 1]) ? 1 : 0);
+    want += 6;
+    if (n != want) return gr_fail(ctx, GR_EINVAL, "gr_model_load_wrn: %d tensors given, %d expected", n, want);
+    for (int i = 0; i < n; i++)
+        if (!t[i]) return gr_fail(ctx, GR_EINVAL, "null tensor %d", i);
+    gr_model* m = new gr_model();
+    m->ctx = ctx; m->kind = 2; m->ncls = ncls;
+    memcpy(m->ch, ch, sizeof(ch));
+    int ti = 0, rc = expect(ctx, numel, 0, 16 * 3 * 9);
+    if (!rc) rc = make_layer(m, &m->wconv1, t[ti++], nullptr, 16, 3, 3, 3, 1, 1);
+    for (int g = 0; g < 3 && !rc; g++)
+        for (int i = 0; i < nb && !rc; i++) {
+            WrnBlock b;
+            b.cin = i == 0 ? ch[g] : ch[g + 1];
+            b.cout = ch[g + 1];
+            b.stride = (i == 0 && g > 0) ? 2 : 1;
+            b.has_sc = b.cin != b.cout;
+            for (int q = 0; q < 4 && !rc; q++) rc = expect(ctx, numel, ti + q, b.cin);
+            if (!rc) rc = make_bn(m, &b.bn1, t[ti], t[ti + 1], t[ti + 2], t[ti + 3], b.cin);
+            ti += 4;
+            if (!rc) rc = expect(ctx, numel, ti, (int64_t)b.cout * b.cin * 9);
+            if (!rc) rc = make_layer(m, &b.conv1, t[ti], nullptr, b.cout, b.cin, 3, 3, b.stride, 1);
+            ti++;
+            for (int q = 0; q < 4 && !rc; q++) rc = expect(ctx, numel, ti + q, b.cout);
+            if (!rc) rc = make_bn(m, &b.bn2, t[ti], t[ti + 1], t[ti + 2], t[ti + 3], b.cout);
+            ti += 4;
+            if (!rc) rc = expect(ctx, numel, ti, (int64_t)b.cout * b.cout * 9);
+            if (!rc) rc = make_layer(m, &b.conv2, t[ti], nullptr, b.cout, b.cout, 3, 3, 1, 1);
+            ti++;
+            if (b.has_sc) {
+                if (!rc) rc = expect(ctx, numel, ti, (int64_t)b.cout * b.cin);
+                if (!rc) rc = make_layer(m, &b.sc, t[ti], nullptr, b.cout, b.cin, 1, 1, b.stride, 0);
+                ti++;
+            }
+            m->blocks.push_back(b);
+        }
+    for (int q = 0; q < 4 && !rc; q++) rc = expect(ctx, numel, ti + q, ch[3]);
+    if (!rc) rc = make_bn(m, &m->bnf, t[ti], t[ti + 1], t[ti + 2], t[ti + 3], ch[3]);
+    ti += 4;
+    if (!rc) rc = expect(ctx, numel, ti, (int64_t)ncls * ch[3]);
+    if (!rc) rc = expect(ctx, numel, ti + 1, ncls);
+    if (!rc) rc = make_layer(m, &m->wfc, t[ti], t[ti + 1], ncls, ch[3], 1, 1, 1, 0);
+    if (rc) { gr_model_destroy(m); return rc; }
+    *out = m;
+    return GR_OK;
+}
+
+extern "C" void gr_model_destroy(gr_model* m) {
+    if (!m) return;
+    for (void* p : m->allocs) (void)hipFree(p);
+    delete m;
+}
+extern "C" int gr_model_num_classes(const gr_model* m) { return m ? m->ncls : GR_EINVAL; }
+
+// ---------------------------------------------------------------------------------------------
+// small kernels
+// ---------------------------------------------------------------------------------------------
+// GTSRBNet conv1_1 (1x1, 3->3) + ReLU fused with the CHW -> NHWC4 layout change (GTSRBNet.py:36).
+// c11 = 9 weights [o][i] + 3 biases.  WITH_CONV=false: layout change only (WideResNet input).
+template <bool WITH_CONV>
+__global__ void k_input_nhwc4(const float* __restrict__ x, const float* __restrict__ c11, int N, float4* __restrict__ out) {
+    int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= N * 1024) return;
+    int n = idx >> 10, p = idx & 1023;
+    const float* xi = x + (size_t)n * 3072 + p;
+    float v0 = xi[0], v1 = xi[1024], v2 = xi[2048];
+    float4 o;
+    if (WITH_CONV) {
+        float r[3];
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            float a = 0.f;
+            a = fmaf(v0, c11[k * 3 + 0], a);
+            a = fmaf(v1, c11[k * 3 + 1], a);
+            a = fmaf(v2, c11[k * 3 + 2], a);
+            a = a + c11[9 + k];
+            r[k] = a > 0.f ? a : 0.f;
+        }
+        o = make_float4(r[0], r[1], r[2], 0.f);
+    } else {
+        o = make_float4(v0, v1, v2, 0.f);
+    }
+    out[idx] = o;
+}
+
+// avg_pool2d(8) over an [N, P, C] NHWC tensor -> [N, C]; sequential sum over pixels, times 1/P
+__global__ void k_avgpool(const float* __restrict__ in, int N, int P, int C, float* __restrict__ out) {
+    int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= N * C) return;
+    int n = idx / C, c = idx % C;
+    const float* s = in + (size_t)n * P * C + c;
+    float sum = 0.f;
+    for (int p = 0; p < P; p++) sum += s[(size_t)p * C];
+    out[idx] = sum * (1.0f / (float)P);
+}
+
+// torch.max(out,1): first maximum.  One lane per image; hits reduced across the wavefront when all
+// 64 lanes belong to one candidate (ballot + popcount -> one atomic), per-lane atomics otherwise.
+__global__ void k_argmax_hits(const float* __restrict__ logits, int N, int ncls, long long n_begin, int T, int target,
+                              int* __restrict__ hits, long long* __restrict__ preds) {
+    int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    bool live = idx < N;
+    int best = 0;
+    if (live) {
+        const float* l = logits + (size_t)idx * ncls;
+        float bv = l[0];
+        for (int c = 1; c < ncls; c++) {
+            float v = l[c];
+            if (v > bv) { bv = v; best = c; }
+        }
+        if (preds) preds[idx] = best;
+    }
+    if (!hits) return;
+    bool hit = live && best == target;
+    long long n = n_begin + idx;
+    int cand = live ? (int)(n / T) : -1;
+    int lane = threadIdx.x & 63;
+    int c0 = __shfl(cand, 0), c63 = __shfl(cand, 63);
+    unsigned long long bal = __ballot(hit);
+    if (c0 == c63 && c0 >= 0) {
+        if (lane == 0 && bal) atomicAdd(&hits[c0], __popcll(bal));
+    } else if (hit) {
+        atomicAdd(&hits[cand], 1);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// layer dispatch
+// ---------------------------------------------------------------------------------------------
+static int run_conv(gr_ctx* ctx, const Layer& L, const float* in, int B, int H, int W, const float* res, const BnDev* act,
+                    float* out_raw, float* out_act, bool relu, bool pool, hipStream_t st) {
+    ConvParams p;
+    p.in = in; p.wgt = L.w; p.bias = L.bias; p.res = res;
+    p.scale = act ? act->scale : nullptr; p.shift = act ? act->shift : nullptr;
+    p.out_raw = out_raw; p.out_act = out_act;
+    p.H = H; p.W = W; p.Cin = L.Cin;
+    p.Ho = (H + 2 * L.pad - L.KH) / L.stride + 1;
+    p.Wo = (W + 2 * L.pad - L.KW) / L.stride + 1;
+    p.Cout = L.Cout; p.NP = L.NP; p.KH = L.KH; p.KW = L.KW; p.stride = L.stride; p.pad = L.pad;
+    long long M = (long long)B * p.Ho * p.Wo;
+    if (M > 0x7fffffff - 512) return gr_fail(ctx, GR_EINVAL, "conv: M too large");
+    p.M = (int)M; p.relu = relu ? 1 : 0;
+    const int K = L.KH * L.KW * L.Cin;
+    const int bn = n_tile(L.Cout);
+    int bk = 0;
+    if (L.Cin % 32 == 0) bk = 32;
+    else if (L.Cin % 16 == 0) bk = 16;
+    else if (L.Cin == 4 && L.KW == 5) bk = 20;
+    else if (L.Cin == 4 && L.KW == 3) bk = 12;
+    if (!bk || K % bk) return gr_fail(ctx, GR_EINVAL, "conv: unsupported Cin=%d K=%d", L.Cin, K);
+    if (pool && ((p.Ho | p.Wo) & 1)) return gr_fail(ctx, GR_EINVAL, "conv: pooled output must be even");
+    hipError_t e = hipErrorInvalidValue;
+#define GO(BK_, WM_, WN_, TM_, TN_, POOL_) e = launch_conv_igemm<BK_, WM_, WN_, TM_, TN_, POOL_>(p, st)
+    if (bn == 32) {
+        if (bk == 32) { if (pool) GO(32, 4, 1, 2, 1, true); else GO(32, 4, 1, 2, 1, false); }
+        else if (bk == 16 && !pool) GO(16, 4, 1, 2, 1, false);
+        else if (bk == 20 && !pool) GO(20, 4, 1, 2, 1, false);
+        else if (bk == 12 && !pool) GO(12, 4, 1, 2, 1, false);
+    } else if (bn == 64) {
+        if (bk == 32) { if (pool) GO(32, 2, 2, 2, 1, true); else GO(32, 2, 2, 2, 1, false); }
+        else if (bk == 16 && !pool) GO(16, 2, 2, 2, 1, false);
+    } else if (bn == 128) {
+        if (bk == 32) { if (pool) GO(32, 2, 2, 2, 2, true); else GO(32, 2, 2, 2, 2, false); }
+        else if (bk == 16 && !pool) GO(16, 2, 2, 2, 2, false);
+    } else if (bn == 160) {
+        if (bk == 32 && !pool) GO(32, 4, 1, 1, 5, false);
+        else if (bk == 16 && !pool) GO(16, 4, 1, 1, 5, false);
+    }
+#undef GO
+    if (e != hipSuccess) return gr_fail(ctx, GR_EHIP, "conv launch (bn=%d bk=%d pool=%d): %s", bn, bk, (int)pool, hipGetErrorString(e));
+    return GR_OK;
+}
+
+// per-image workspace in floats
+static size_t per_image_floats(const gr_model* m) {
+    if (m->kind == 1) return 4096 + 32768 + 8192;                  // x4 + bufA + bufB
+    size_t big = (size_t)1024 * m->ch[1];
+    if ((size_t)256 * m->ch[2] > big) big = (size_t)256 * m->ch[2];
+    return 4096 + 5 * big;                                          // x4 + x, o, u, s, y
+}
+size_t net_workspace_bytes(const gr_model* m, int N) { return gr_align(per_image_floats(m) * sizeof(float) * (size_t)N); }
+
+static int gtsrb_forward(gr_ctx* ctx, gr_model* m, const float* x, int N, float* logits, float* ws, hipStream_t st) {
+    float* x4 = ws;
+    float* A = x4 + (size_t)N * 4096;
+    float* Bf = A + (size_t)N * 32768;
+    hipLaunchKernelGGL(k_input_nhwc4<true>, dim3((N * 1024 + 255) / 256), dim3(256), 0, st, x, m->c11, N, (float4*)x4);
+    GR_HIP(ctx, hipGetLastError());
+    int rc;
+    if ((rc = run_conv(ctx, m->g[0], x4, N, 32, 32, nullptr, nullptr, A, nullptr, true, false, st))) return rc;   // conv2_1
+    if ((rc = run_conv(ctx, m->g[1], A, N, 32, 32, nullptr, nullptr, Bf, nullptr, true, true, st))) return rc;    // conv2_2+pool
+    if ((rc = run_conv(ctx, m->g[2], Bf, N, 16, 16, nullptr, nullptr, A, nullptr, true, false, st))) return rc;   // conv3_1
+    if ((rc = run_conv(ctx, m->g[3], A, N, 16, 16, nullptr, nullptr, Bf, nullptr, true, true, st))) return rc;    // conv3_2+pool
+    if ((rc = run_conv(ctx, m->g[4], Bf, N, 8, 8, nullptr, nullptr, A, nullptr, true, false, st))) return rc;     // conv4_1
+    if ((rc = run_conv(ctx, m->g[5], A, N, 8, 8, nullptr, nullptr, Bf, nullptr, true, true, st))) return rc;      // conv4_2+pool
+    if ((rc = run_conv(ctx, m->g[6], Bf, N, 1, 1, nullptr, nullptr, A, nullptr, true, false, st))) return rc;     // fc5
+    if ((rc = run_conv(ctx, m->g[7], A, N, 1, 1, nullptr, nullptr, Bf, nullptr, true, false, st))) return rc;     // fc6
+    return run_conv(ctx, m->g[8], Bf, N, 1, 1, nullptr, nullptr, logits, nullptr, false, false, st);             // fc7
+}
+
+static int wrn_forward(gr_ctx* ctx, gr_model* m, const float* x, int N, float* logits, float* ws, hipStream_t st) {
+    size_t big = (size_t)1024 * m->ch[1];
+    if ((size_t)256 * m->ch[2] > big) big = (size_t)256 * m->ch[2];
+    float* x4 = ws;
+    float* xr = x4 + (size_t)N * 4096;       // raw block input (residual)
+    float* o = xr + (size_t)N * big;         // relu(bn1(x))
+    float* u = o + (size_t)N * big;          // relu(bn2(conv1))
+    float* s = u + (size_t)N * big;          // shortcut conv
+    float* y = s + (size_t)N * big;          // next raw
+    hipLaunchKernelGGL(k_input_nhwc4<false>, dim3((N * 1024 + 255) / 256), dim3(256), 0, st, x, (const float*)nullptr, N,
+                       (float4*)x4);
+    GR_HIP(ctx, hipGetLastError());
+    int rc;
+    const size_t nb = m->blocks.size();
+    // conv1 -> raw x (block1.0 needs it only if equalInOut) and o = relu(bn1_0(x))
+    if ((rc = run_conv(ctx, m->wconv1, x4, N, 32, 32, nullptr, &m->blocks[0].bn1, m->blocks[0].has_sc ? nullptr : xr, o,
+                       false, false, st))) return rc;
+    int H = 32;
+    for (size_t bi = 0; bi < nb; bi++) {
+        WrnBlock& b = m->blocks[bi];
+        int Ho = H / b.stride;
+        if ((rc = run_conv(ctx, b.conv1, o, N, H, H, nullptr, &b.bn2, nullptr, u, false, false, st))) return rc;
+        const float* res = xr;
+        if (b.has_sc) {
+            if ((rc = run_conv(ctx, b.sc, o, N, H, H, nullptr, nullptr, s, nullptr, false, false, st))) return rc;
+            res = s;
+        }
+        bool last = bi + 1 == nb;
+        const BnDev* nbn = last ? &m->bnf : &m->blocks[bi + 1].bn1;
+        bool need_raw = !last && !m->blocks[bi + 1].has_sc;
+        // o is free once conv1 and the shortcut have consumed it: the activated output goes there
+        if ((rc = run_conv(ctx, b.conv2, u, N, Ho, Ho, res, nbn, need_raw ? y : nullptr, o, false, false, st))) return rc;
+        if (need_raw) { float* tmp = xr; xr = y; y = tmp; }
+        H = Ho;
+    }
+    int C = m->ch[3];
+    hipLaunchKernelGGL(k_avgpool, dim3((N * C + 255) / 256), dim3(256), 0, st, o, N, H * H, C, u);
+    GR_HIP(ctx, hipGetLastError());
+    return run_conv(ctx, m->wfc, u, N, 1, 1, nullptr, nullptr, logits, nullptr, false, false, st);
+}
+
+int net_forward(gr_ctx* ctx, gr_model* m, const float* x, int N, float* logits, char* ws, size_t ws_bytes, hipStream_t st) {
+    if (N <= 0) return GR_OK;
+    if (ws_bytes < net_workspace_bytes(m, N)) return gr_fail(ctx, GR_ESTATE, "net_forward: workspace too small");
+    if (m->kind == 1) return gtsrb_forward(ctx, m, x, N, logits, (float*)ws, st);
+    if (m->kind == 2) return wrn_forward(ctx, m, x, N, logits, (float*)ws, st);
+    return gr_fail(ctx, GR_ESTATE, "unknown model kind");
+}
+
+int net_hits(gr_ctx* ctx, const float* logits, int N, int ncls, int64_t n_begin, int T, int target, int32_t* hits,
+             int64_t* preds, hipStream_t st) {
+    if (N <= 0) return GR_OK;
+    hipLaunchKernelGGL(k_argmax_hits, dim3((N + 255) / 256), dim3(256), 0, st, logits, N, ncls, (long long)n_begin, T,
+                       target, (int*)hits, (long long*)preds);
+    GR_HIP(ctx, hipGetLastError());
+    return GR_OK;
+}
+int net_argmax(gr_ctx* ctx, const float* logits, int N, int ncls, int64_t* preds, hipStream_t st) {
+    return net_hits(ctx, logits, N, ncls, 0, 1, -1, nullptr, preds, st);
+}

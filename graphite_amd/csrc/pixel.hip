@@ -1,0 +1,385 @@
+// pixel.hip -- the image half of the transform-robustness path, hand-written for gfx950.
+//
+//   k_composite   add_noise (transforms.py:143-159) + GaussianBlur/where/clip (transforms.py:55-62)
+//                 fused per 32x32 tile; one RGBX f32 composite per (candidate, blur kernel).
+//   k_warp_net    warpPerspective (perspective_transform.py:47) + gamma LUT (transforms.py:69-75)
+//                 + resize to net x net + clamp + normalise (transforms.py:18-29), fused, and
+//                 evaluated ON DEMAND: the resize reads a 2x2 neighbourhood of the warp per output
+//                 pixel, so only <= 4*net*net of the (up to 275x275) warped pixels are computed.
+//   k_resize, k_add_noise, k_warp_full: the same operators as stand-alone calls.
+//
+// Arithmetic is float32 / float64 in the exact operation order of oracle/graphite_oracle.c; this file
+// is compiled with -ffp-contract=off so that no mul+add pair is fused behind its back.
+// Everything here is bandwidth / gather work: no MFMA, coalesced 16-byte accesses, LDS for the
+// blur stencil and the LUT.
+#include "common.h"
+
+namespace {
+
+struct Tap { int i0, i1; float w0, w1; };
+
+// cv::resize INTER_LINEAR tap.  scale = 1.0/((double)dsize/ssize) (host).
+__device__ __forceinline__ Tap tap_h(int d, int ssize, double scale) {
+    float f = (float)((d + 0.5) * scale - 0.5);
+    int s = (int)floorf(f);
+    f -= (float)s;
+    if (s < 0) { f = 0.f; s = 0; }
+    if (s >= ssize - 1) { f = 0.f; s = ssize - 1; }
+    Tap t;
+    t.i0 = s;
+    t.i1 = s + 1 < ssize ? s + 1 : ssize - 1;
+    t.w0 = 1.f - f;
+    t.w1 = f;
+    return t;
+}
+__device__ __forceinline__ int clipi(int x, int a, int b) { return x >= a ? (x < b ? x : b - 1) : a; }
+__device__ __forceinline__ Tap tap_v(int d, int ssize, double scale) {
+    float f = (float)((d + 0.5) * scale - 0.5);
+    int s = (int)floorf(f);
+    f -= (float)s;
+    Tap t;
+    t.i0 = clipi(s, 0, ssize);
+    t.i1 = clipi(s + 1, 0, ssize);
+    t.w0 = 1.f - f;
+    t.w1 = f;
+    return t;
+}
+__device__ __forceinline__ float bilerp(const float* __restrict__ p, int sw, const Tap& tx, const Tap& ty) {
+    float h0 = p[ty.i0 * sw + tx.i0] * tx.w0 + p[ty.i0 * sw + tx.i1] * tx.w1;
+    float h1 = p[ty.i1 * sw + tx.i0] * tx.w0 + p[ty.i1 * sw + tx.i1] * tx.w1;
+    return h0 * ty.w0 + h1 * ty.w1;
+}
+__device__ __forceinline__ float clamp01(float v) { return v < 0.f ? 0.f : (v > 1.f ? 1.f : v); }
+__device__ __forceinline__ int refl101(int i, int n) {
+    if (n == 1) return 0;
+    while (i < 0 || i >= n) { if (i < 0) i = -i; else i = 2 * n - 2 - i; }
+    return i;
+}
+
+// ---------------------------------------------------------------------------------------------
+// stand-alone resize (+ optional clamp / -0.5)
+// ---------------------------------------------------------------------------------------------
+__global__ void k_resize(const float* __restrict__ src, int C, int sh, int sw, float* __restrict__ dst, int dh, int dw,
+                         double sx, double sy, int clamp, int normalize) {
+    int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    int total = C * dh * dw;
+    if (idx >= total) return;
+    int c = idx / (dh * dw), r = idx % (dh * dw), y = r / dw, x = r % dw;
+    const float* p = src + (size_t)c * sh * sw;
+    float v;
+    if (sh == dh && sw == dw) v = p[y * sw + x];
+    else v = bilerp(p, sw, tap_h(x, sw, sx), tap_v(y, sh, sy));
+    if (clamp) v = clamp01(v);
+    if (normalize) v = v - 0.5f;
+    dst[idx] = v;
+}
+
+// ---------------------------------------------------------------------------------------------
+// stand-alone add_noise
+// ---------------------------------------------------------------------------------------------
+__global__ void k_add_noise(const float* __restrict__ img, int H, int W, const float* __restrict__ mask,
+                            const float* __restrict__ theta, int nh, int nw, double sx, double sy, float lbd, int clip,
+                            float* comb, float* pert, float* mask_lg) {
+    int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    int total = 3 * H * W;
+    if (idx >= total) return;
+    int c = idx / (H * W), r = idx % (H * W), y = r / W, x = r % W;
+    Tap tx = tap_h(x, nw, sx), ty = tap_v(y, nh, sy);
+    bool same = (nh == H && nw == W);
+    float th = same ? theta[idx] : bilerp(theta + c * nh * nw, nw, tx, ty);
+    float ml = same ? mask[idx] : bilerp(mask + c * nh * nw, nw, tx, ty);
+    float v = img[idx] + lbd * th;
+    float m = ml > 0.5f ? 1.f : 0.f;
+    if (clip) v = clamp01(v);
+    if (comb) comb[idx] = v;
+    if (pert) pert[idx] = m > 0.5f ? v : 0.f;
+    if (mask_lg) mask_lg[idx] = m;
+}
+
+// ---------------------------------------------------------------------------------------------
+// composite: per 32x32 tile (+3 halo) of one candidate, every blur variant the table uses.
+// ---------------------------------------------------------------------------------------------
+constexpr int CT = 32;          // tile edge
+constexpr int CHALO = 3;        // max blur radius (k=7)
+constexpr int CE = CT + 2 * CHALO;   // 38
+constexpr int CEP = CE + 1;     // padded row
+
+__device__ __forceinline__ float rowf(const float* s, int k) {   // s points at the centre tap
+    if (k == 3) return s[0] * 0.5f + (s[-1] + s[1]) * 0.25f;
+    if (k == 5) return s[0] * 0.375f + (s[-1] + s[1]) * 0.25f + (s[-2] + s[2]) * 0.0625f;
+    float v = 0.03125f * s[-3];
+    v += 0.109375f * s[-2];
+    v += 0.21875f * s[-1];
+    v += 0.28125f * s[0];
+    v += 0.21875f * s[1];
+    v += 0.109375f * s[2];
+    v += 0.03125f * s[3];
+    return v;
+}
+__device__ __forceinline__ float colf(const float* s, int stride, int k) {   // s points at the centre tap
+    if (k == 3) return s[0] * 0.5f + (s[-stride] + s[stride]) * 0.25f;
+    if (k == 5) {
+        float v = 0.375f * s[0];
+        v += 0.25f * (s[stride] + s[-stride]);
+        v += 0.0625f * (s[2 * stride] + s[-2 * stride]);
+        return v;
+    }
+    float v = 0.28125f * s[0];
+    v += 0.21875f * (s[stride] + s[-stride]);
+    v += 0.109375f * (s[2 * stride] + s[-2 * stride]);
+    v += 0.03125f * (s[3 * stride] + s[-3 * stride]);
+    return v;
+}
+
+template <bool FROM_PERT>
+__global__ __launch_bounds__(256) void k_composite(const float* __restrict__ img, int H, int W,
+                                                   const float* __restrict__ masks, const float* __restrict__ thetas,
+                                                   int nh, int nw, double sx, double sy, float lbd, int nslots, int b0,
+                                                   int b1, int b2, int b3, float* __restrict__ att) {
+    __shared__ float s_pert[3][CE][CEP];
+    __shared__ float s_tmp[3][CE][CT];
+    __shared__ unsigned char s_msk[3][CE][CEP];
+    const int tiles_x = (W + CT - 1) / CT;
+    const int tx0 = (blockIdx.x % tiles_x) * CT, ty0 = (blockIdx.x / tiles_x) * CT;
+    const int cand = blockIdx.y;
+    const int tid = threadIdx.x;
+    const size_t pl = (size_t)H * W;
+    const float* mask = masks + (FROM_PERT ? 0 : (size_t)cand * 3 * nh * nw);
+    const float* theta = thetas + (FROM_PERT ? 0 : (size_t)cand * 3 * nh * nw);
+
+    // (a) pert and mask bits on the haloed tile; out-of-image coordinates reflect (BORDER_REFLECT_101)
+    for (int i = tid; i < CE * CE; i += 256) {
+        int ly = i / CE, lx = i % CE;
+        int gy = refl101(ty0 + ly - CHALO, H), gx = refl101(tx0 + lx - CHALO, W);
+        if (FROM_PERT) {
+            for (int c = 0; c < 3; c++) {
+                s_pert[c][ly][lx] = thetas[c * pl + (size_t)gy * W + gx];           // thetas == pert here
+                s_msk[c][ly][lx] = masks[c * pl + (size_t)gy * W + gx] > 0.5f;      // masks == mask_lg here
+            }
+        } else {
+            Tap tx = tap_h(gx, nw, sx), ty = tap_v(gy, nh, sy);
+            for (int c = 0; c < 3; c++) {
+                float th = bilerp(theta + c * nh * nw, nw, tx, ty);
+                float ml = bilerp(mask + c * nh * nw, nw, tx, ty);
+                float v = clamp01(img[c * pl + (size_t)gy * W + gx] + lbd * th);
+                bool m = ml > 0.5f;
+                s_pert[c][ly][lx] = m ? v : 0.f;
+                s_msk[c][ly][lx] = m;
+            }
+        }
+    }
+    __syncthreads();
+
+    const int blurs[4] = {b0, b1, b2, b3};
+    for (int s = 0; s < nslots; s++) {
+        const int k = blurs[s];
+        if (k != 0) {
+            for (int i = tid; i < 3 * CE * CT; i += 256) {          // row pass on all 38 rows
+                int c = i / (CE * CT), r = i % (CE * CT), ly = r / CT, x = r % CT;
+                s_tmp[c][ly][x] = rowf(&s_pert[c][ly][x + CHALO], k);
+            }
+            __syncthreads();
+        }
+        float* dst = att + ((size_t)cand * nslots + s) * pl * 4;
+        for (int j = 0; j < 4; j++) {
+            int y = tid / CT + 8 * j, x = tid % CT;
+            int gy = ty0 + y, gx = tx0 + x;
+            if (gy < H && gx < W) {
+                float o[3];
+                for (int c = 0; c < 3; c++) {
+                    float v = (k == 0) ? s_pert[c][y + CHALO][x + CHALO] : colf(&s_tmp[c][y + CHALO][x], CT, k);
+                    float base = img[c * pl + (size_t)gy * W + gx];
+                    o[c] = clamp01(s_msk[c][y + CHALO][x + CHALO] ? v : base);
+                }
+                *reinterpret_cast<float4*>(dst + ((size_t)gy * W + gx) * 4) = make_float4(o[0], o[1], o[2], 0.f);
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// warp sampling
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ int cv_round_sat(double v) {
+    v = fmax(v, -2147483648.0);
+    v = fmin(v, 2147483647.0);
+    return (int)rint(v);
+}
+__device__ __forceinline__ int sat_short(int v) { return v < -32768 ? -32768 : (v > 32767 ? 32767 : v); }
+
+struct WarpTaps { int o00, o01, o10, o11; float w0, w1, w2, w3; };
+
+// cv::warpPerspective coordinate + weight computation for dst pixel (x,y)
+__device__ __forceinline__ WarpTaps warp_taps(const double* Mi, int bw0, int x, int y, int H, int W) {
+    int xb = (x / bw0) * bw0, x1 = x - xb;
+    double X0 = Mi[0] * xb + Mi[1] * y + Mi[2];
+    double Y0 = Mi[3] * xb + Mi[4] * y + Mi[5];
+    double W0 = Mi[6] * xb + Mi[7] * y + Mi[8];
+    double Wd = W0 + Mi[6] * x1;
+    Wd = 32.0 * (Wd != 0.0 ? 1.0 / Wd : 0.0);
+    int X = cv_round_sat((X0 + Mi[0] * x1) * Wd);
+    int Y = cv_round_sat((Y0 + Mi[3] * x1) * Wd);
+    int sx = sat_short(X >> 5), sy = sat_short(Y >> 5);
+    float fx = (float)(X & 31) * (1.f / 32.f), fy = (float)(Y & 31) * (1.f / 32.f);
+    WarpTaps t;
+    t.w0 = (1.f - fy) * (1.f - fx);
+    t.w1 = (1.f - fy) * fx;
+    t.w2 = fy * (1.f - fx);
+    t.w3 = fy * fx;
+    int sx0 = clipi(sx, 0, W), sx1 = clipi(sx + 1, 0, W), sy0 = clipi(sy, 0, H), sy1 = clipi(sy + 1, 0, H);
+    t.o00 = sy0 * W + sx0;
+    t.o01 = sy0 * W + sx1;
+    t.o10 = sy1 * W + sx0;
+    t.o11 = sy1 * W + sx1;
+    return t;
+}
+
+__device__ __forceinline__ float gamma_stage(float v, const unsigned char* lut) {
+    float s = v * 255.0f;
+    int u = ((int)s) & 255;
+    float r = (float)((double)lut[u] / 255.0);
+    return clamp01(r);
+}
+
+// warped + gamma'd pixel from an RGBX composite
+__device__ __forceinline__ void warp_gamma_rgbx(const float4* __restrict__ att, const double* Mi, int bw0, int x, int y,
+                                                int H, int W, const unsigned char* lut, float* o3) {
+    WarpTaps t = warp_taps(Mi, bw0, x, y, H, W);
+    float4 a = att[t.o00], b = att[t.o01], c = att[t.o10], d = att[t.o11];
+    o3[0] = gamma_stage(a.x * t.w0 + b.x * t.w1 + c.x * t.w2 + d.x * t.w3, lut);
+    o3[1] = gamma_stage(a.y * t.w0 + b.y * t.w1 + c.y * t.w2 + d.y * t.w3, lut);
+    o3[2] = gamma_stage(a.z * t.w0 + b.z * t.w1 + c.z * t.w2 + d.z * t.w3, lut);
+}
+
+// One workgroup per image n = (candidate, transform).
+__global__ __launch_bounds__(256) void k_warp_net(const float* __restrict__ att_all, int H, int W, int nslots,
+                                                  const XformDev* __restrict__ xf, int T, long long n_begin, int cand0,
+                                                  int normalize, int net, float* __restrict__ out) {
+    __shared__ double s_Mi[9];
+    __shared__ unsigned char s_lut[256];
+    __shared__ int s_par[4];
+    const long long n = n_begin + blockIdx.x;
+    const int cand = (int)(n / T) - cand0, t = (int)(n % T);
+    const XformDev* x = xf + t;
+    const int tid = threadIdx.x;
+    if (tid < 9) s_Mi[tid] = x->Mi[tid];
+    if (tid >= 64 && tid < 128) reinterpret_cast<unsigned int*>(s_lut)[tid - 64] = reinterpret_cast<const unsigned int*>(x->lut)[tid - 64];
+    if (tid == 128) { s_par[0] = x->crop_x; s_par[1] = x->crop_y; s_par[2] = x->slot; s_par[3] = x->bw0; }
+    __syncthreads();
+    const int cw = s_par[0], ch = s_par[1], bw0 = s_par[3];
+    const size_t pl = (size_t)H * W;
+    const float4* att = reinterpret_cast<const float4*>(att_all) + ((size_t)cand * nslots + s_par[2]) * pl;
+    const double scx = 1.0 / ((double)net / (double)cw), scy = 1.0 / ((double)net / (double)ch);
+    const bool same = (cw == net && ch == net);
+    float* o = out + (size_t)blockIdx.x * 3 * net * net;
+    for (int p = tid; p < net * net; p += 256) {
+        int oy = p / net, ox = p % net;
+        float r[3];
+        if (same) {
+            warp_gamma_rgbx(att, s_Mi, bw0, ox, oy, H, W, s_lut, r);
+        } else {
+            Tap tx = tap_h(ox, cw, scx), ty = tap_v(oy, ch, scy);
+            float g00[3], g01[3], g10[3], g11[3];
+            warp_gamma_rgbx(att, s_Mi, bw0, tx.i0, ty.i0, H, W, s_lut, g00);
+            warp_gamma_rgbx(att, s_Mi, bw0, tx.i1, ty.i0, H, W, s_lut, g01);
+            warp_gamma_rgbx(att, s_Mi, bw0, tx.i0, ty.i1, H, W, s_lut, g10);
+            warp_gamma_rgbx(att, s_Mi, bw0, tx.i1, ty.i1, H, W, s_lut, g11);
+            for (int c = 0; c < 3; c++) {
+                float h0 = g00[c] * tx.w0 + g01[c] * tx.w1;
+                float h1 = g10[c] * tx.w0 + g11[c] * tx.w1;
+                r[c] = h0 * ty.w0 + h1 * ty.w1;
+            }
+        }
+        for (int c = 0; c < 3; c++) {
+            float v = clamp01(r[c]);
+            o[c * net * net + p] = normalize ? v - 0.5f : v;
+        }
+    }
+}
+
+// stand-alone warpPerspective, planar src -> planar dst (no gamma)
+__global__ void k_warp_full(const float* __restrict__ src, int H, int W, double m0, double m1, double m2, double m3,
+                            double m4, double m5, double m6, double m7, double m8, int bw0, int cw, int ch,
+                            float* __restrict__ dst) {
+    int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= cw * ch) return;
+    int y = idx / cw, x = idx % cw;
+    double Mi[9] = {m0, m1, m2, m3, m4, m5, m6, m7, m8};
+    WarpTaps t = warp_taps(Mi, bw0, x, y, H, W);
+    size_t pl = (size_t)H * W, cpl = (size_t)cw * ch;
+    for (int c = 0; c < 3; c++) {
+        const float* p = src + c * pl;
+        dst[c * cpl + idx] = p[t.o00] * t.w0 + p[t.o01] * t.w1 + p[t.o10] * t.w2 + p[t.o11] * t.w3;
+    }
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------
+// launchers
+// ---------------------------------------------------------------------------------------------
+static inline double inv_scale(int ssize, int dsize) { return 1.0 / ((double)dsize / (double)ssize); }
+
+int px_resize(gr_ctx* ctx, const float* src, int C, int sh, int sw, float* dst, int dh, int dw, int clamp, int normalize,
+              hipStream_t st) {
+    int total = C * dh * dw;
+    hipLaunchKernelGGL(k_resize, dim3((total + 255) / 256), dim3(256), 0, st, src, C, sh, sw, dst, dh, dw,
+                       inv_scale(sw, dw), inv_scale(sh, dh), clamp, normalize);
+    GR_HIP(ctx, hipGetLastError());
+    return GR_OK;
+}
+
+int px_add_noise(gr_ctx* ctx, const float* img, int H, int W, const float* mask, const float* theta, int nh, int nw,
+                 float lbd, int clip, float* comb, float* pert, float* mask_lg, hipStream_t st) {
+    int total = 3 * H * W;
+    hipLaunchKernelGGL(k_add_noise, dim3((total + 255) / 256), dim3(256), 0, st, img, H, W, mask, theta, nh, nw,
+                       inv_scale(nw, W), inv_scale(nh, H), lbd, clip, comb, pert, mask_lg);
+    GR_HIP(ctx, hipGetLastError());
+    return GR_OK;
+}
+
+int px_warp_full(gr_ctx* ctx, const float* src, int H, int W, const double* Mi, int crop_x, int crop_y, float* dst,
+                 hipStream_t st) {
+    int bh0 = 16 < crop_y ? 16 : crop_y;
+    int bw0 = 1024 / bh0;
+    if (bw0 > crop_x) bw0 = crop_x;
+    int total = crop_x * crop_y;
+    hipLaunchKernelGGL(k_warp_full, dim3((total + 255) / 256), dim3(256), 0, st, src, H, W, Mi[0], Mi[1], Mi[2], Mi[3],
+                       Mi[4], Mi[5], Mi[6], Mi[7], Mi[8], bw0, crop_x, crop_y, dst);
+    GR_HIP(ctx, hipGetLastError());
+    return GR_OK;
+}
+
+int px_composite(gr_ctx* ctx, const float* img, int H, int W, const float* masks, const float* thetas, int ncand,
+                 int nh, int nw, float lbd, const gr_xforms* xf, float* att, hipStream_t st) {
+    if (ncand <= 0) return GR_OK;
+    int tiles = ((W + CT - 1) / CT) * ((H + CT - 1) / CT);
+    for (int c0 = 0; c0 < ncand; c0 += 32768) {        // gridDim.y limit
+        int nc = ncand - c0 < 32768 ? ncand - c0 : 32768;
+        hipLaunchKernelGGL(k_composite<false>, dim3(tiles, nc), dim3(256), 0, st, img, H, W,
+                           masks + (size_t)c0 * 3 * nh * nw, thetas + (size_t)c0 * 3 * nh * nw, nh, nw,
+                           inv_scale(nw, W), inv_scale(nh, H), lbd, xf->nslots, xf->slot_blur[0], xf->slot_blur[1],
+                           xf->slot_blur[2], xf->slot_blur[3], att + (size_t)c0 * xf->nslots * H * W * 4);
+    }
+    GR_HIP(ctx, hipGetLastError());
+    return GR_OK;
+}
+
+int px_composite_from_pert(gr_ctx* ctx, const float* img, const float* mask_lg, const float* pert, int H, int W,
+                           const gr_xforms* xf, float* att, hipStream_t st) {
+    int tiles = ((W + CT - 1) / CT) * ((H + CT - 1) / CT);
+    hipLaunchKernelGGL(k_composite<true>, dim3(tiles, 1), dim3(256), 0, st, img, H, W, mask_lg, pert, H, W, 1.0, 1.0,
+                       1.0f, xf->nslots, xf->slot_blur[0], xf->slot_blur[1], xf->slot_blur[2], xf->slot_blur[3], att);
+    GR_HIP(ctx, hipGetLastError());
+    return GR_OK;
+}
+
+int px_warp_net(gr_ctx* ctx, const float* att, int H, int W, const gr_xforms* xf, int64_t n_begin, int count, int cand0,
+                int normalize, int net, float* out_chw, hipStream_t st) {
+    if (count <= 0) return GR_OK;
+    hipLaunchKernelGGL(k_warp_net, dim3(count), dim3(256), 0, st, att, H, W, xf->nslots, xf->dev, xf->T,
+                       (long long)n_begin, cand0, normalize, net, out_chw);
+    GR_HIP(ctx, hipGetLastError());
+    return GR_OK;
+}

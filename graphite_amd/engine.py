@@ -1,0 +1,76 @@
+"""Fused, batched transform-robustness evaluation (the entry the batched search drivers use).
+
+`tr_hits(...)` == for every candidate c:
+    imgs = get_transformed_images(image, masks[c], transforms, lbd, thetas[c], pt_file, 32, model_type)
+    err, n = run_predictions(model, imgs, label, target)         # reference utils.py:60
+    hits[c] = round((1 - err) * n)
+but in one pass over C x T images on the GPU; with torch.distributed initialised the flattened
+(candidate x transform) index space is split evenly over the ranks and the per-candidate counts
+are summed with ONE int32[C] all-reduce (RCCL over xGMI on a GPU node, gloo in the CPU tests).
+"""
+import numpy as np
+import torch
+
+from . import _hip
+from .transforms import build_xform_table, XFORM_DTYPE
+
+
+def shard_range(total, rank, world):
+    """Contiguous, balanced slice [begin, begin+count) of `total` items for `rank` of `world`."""
+    base, rem = divmod(int(total), int(world))
+    begin = rank * base + min(rank, rem)
+    return begin, base + (1 if rank < rem else 0)
+
+
+def allreduce_hits(hits, group=None):
+    """Sum the per-candidate partial counts over the ranks (no-op without torch.distributed)."""
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.all_reduce(hits, op=dist.ReduceOp.SUM, group=group)
+    return hits
+
+
+def _as_table(transforms, w, h, pt_file):
+    if isinstance(transforms, _hip.XformTable):
+        return transforms
+    if isinstance(transforms, np.ndarray) and transforms.dtype == XFORM_DTYPE:
+        return transforms
+    return build_xform_table(transforms, w, h, pt_file)
+
+
+def tr_hits(model, image, masks, thetas, transforms, target, pt_file='inputs/GTSRB/Points/14.csv', lbd=1.0,
+            model_type='GTSRB', distributed=True, return_preds=False):
+    """hits[c] = number of the T transformed images of candidate c classified as `target`.
+
+    image [3,H,W]; masks, thetas [C,3,h,w] (CPU or CUDA tensors / numpy); transforms = the list from
+    get_transform_params, a table from build_xform_table, or a cached _hip.XformTable.
+    Returns an int32 CUDA tensor [C] (and int64 predictions [C,T] if return_preds; with sharding
+    each rank's predictions cover its own slice, -1 elsewhere).
+    """
+    hip_model = getattr(model, "hip_model", model)
+    img = _hip.to_dev(image)
+    tab = _as_table(transforms, img.shape[2], img.shape[1], pt_file)
+    m, t = _hip.to_dev(masks), _hip.to_dev(thetas)
+    if m.dim() == 3:
+        m, t = m[None], t[None]
+    xf = _hip.xform_table(tab)
+    total = m.shape[0] * xf.T
+    begin, count = 0, total
+    import torch.distributed as dist
+    sharded = distributed and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+    if sharded:
+        begin, count = shard_range(total, dist.get_rank(), dist.get_world_size())
+    hits, preds, _ = _hip.tr_hits_dev(hip_model, img, m, t, xf, float(lbd), model_type == 'GTSRB', int(target),
+                                      begin, count, want_preds=return_preds)
+    if sharded:
+        allreduce_hits(hits)
+    if return_preds:
+        return hits, preds.view(m.shape[0], xf.T)
+    return hits
+
+
+def tr_error_rates(model, image, masks, thetas, transforms, target, **kw):
+    """[(error_rate, queries)] per candidate, in run_predictions' convention (utils.py:57)."""
+    hits = tr_hits(model, image, masks, thetas, transforms, target, **kw).cpu().numpy()
+    T = len(transforms) if not isinstance(transforms, _hip.XformTable) else transforms.T
+    return [(1.0 - int(h) * 1.0 / T, T) for h in hits]

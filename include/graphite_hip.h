@@ -1,0 +1,124 @@
+/*
+ * graphite_hip.h -- C ABI of libgraphite_hip.so: GRAPHITE's transform-robustness (TR) scoring
+ * path on MI355X (gfx950).
+ *
+ * The reference (ryan-feng/GRAPHITE, /root/reference) is pure Python and has no FFI of its own;
+ * its de-facto boundary for this path is the pair
+ *     transforms.get_transformed_images(...)   transforms.py:162
+ *     utils.run_predictions(model, imgs, ...)  utils.py:60
+ * plus the helpers they call.  Each entry point below names the reference function (file:line)
+ * whose arithmetic it replaces.  The Python package graphite_amd/ binds these with ctypes and
+ * re-exports the reference's own function names (INTEGRATION.md shows the binding).
+ *
+ * Conventions
+ *  - Plain C: pointers + sizes only, no C++/torch types.  Returns 0 on success, a negative
+ *    GR_E* code otherwise; gr_last_error() gives the message.  No exception crosses the ABI.
+ *  - "dev" pointers are device (HBM) addresses on the context's GPU; "host" pointers are
+ *    ordinary host memory.  The caller owns every buffer it passes; the library owns gr_ctx,
+ *    gr_xforms and gr_model objects and a growable device workspace inside gr_ctx.
+ *  - `stream` is a hipStream_t passed as void* (NULL = the null stream).  Calls enqueue work
+ *    on it and return without synchronising unless stated; one host thread per gr_ctx.
+ *  - Images are planar CHW float32.  Candidate c = (mask[c], theta[c]); image n = c*T + t.
+ */
+#ifndef GRAPHITE_HIP_H
+#define GRAPHITE_HIP_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GR_OK 0
+#define GR_EINVAL (-1)   /* bad argument (null pointer, bad size, unsupported blur, ...) */
+#define GR_EHIP (-2)     /* a HIP runtime call failed */
+#define GR_ENOMEM (-3)   /* device workspace allocation failed */
+#define GR_ESTATE (-4)   /* object used with the wrong context / not initialised */
+
+typedef struct gr_ctx gr_ctx;
+typedef struct gr_model gr_model;
+typedef struct gr_xforms gr_xforms;
+
+/* One sampled transform, as the reference computes it per call:
+ *   M, crop   perspective_transform.py:11-44 (forward src->dst matrix and dsize given to
+ *             cv2.warpPerspective, :47)
+ *   blur      transforms.py:55-56 (Gaussian kernel size 0/3/5/7)
+ *   lut       transforms.py:70-72 (gamma table) */
+typedef struct gr_xform {
+    double M[9];
+    int32_t crop_x, crop_y;
+    int32_t blur;
+    int32_t pad_;
+    uint8_t lut[256];
+} gr_xform;
+
+/* ---- context ------------------------------------------------------------------------------- */
+int gr_ctx_create(int device, gr_ctx** out);
+void gr_ctx_destroy(gr_ctx* ctx);
+/* Message of the last failing call on ctx (ctx == NULL: last gr_ctx_create failure). */
+const char* gr_last_error(const gr_ctx* ctx);
+/* Images classified per internal chunk of gr_tr_hits (default 8192; bounds the workspace). */
+int gr_ctx_set_chunk(gr_ctx* ctx, int images_per_chunk);
+/* Bytes of device workspace currently held. */
+int64_t gr_ctx_workspace_bytes(const gr_ctx* ctx);
+
+/* ---- transform table ------------------------------------------------------------------------
+ * Uploads T descriptors once (inverse matrices are formed in double on the host, as
+ * cv2.warpPerspective does before warping); reused by every call of an attack. */
+int gr_xforms_create(gr_ctx* ctx, const gr_xform* host_xf, int T, gr_xforms** out);
+void gr_xforms_destroy(gr_xforms* xf);
+
+/* ---- pixel operators (all pointers dev) ----------------------------------------------------- */
+/* cv2.resize(src,(dw,dh)) INTER_LINEAR on C planes: transforms.py:23,148,151; boost.py:33,42. */
+int gr_resize_linear(gr_ctx* ctx, const float* src, int C, int sh, int sw, float* dst, int dh, int dw, void* stream);
+/* convert2Network, transforms.py:18-29: resize to net x net, clamp [0,1], minus 0.5 if normalize. */
+int gr_convert_to_network(gr_ctx* ctx, const float* src, int sh, int sw, float* dst, int net, int normalize,
+                          void* stream);
+/* add_noise, transforms.py:143-159.  comb / pert / mask_lg are [3,H,W] outputs, any may be NULL. */
+int gr_add_noise(gr_ctx* ctx, const float* img, int H, int W, const float* mask, const float* theta, int nh, int nw,
+                 float lbd, int clip, float* comb, float* pert, float* mask_lg, void* stream);
+/* cv2.warpPerspective(img, M, (crop_x,crop_y), BORDER_REPLICATE), perspective_transform.py:47.
+ * M = 9 host doubles (forward matrix); dst = [3,crop_y,crop_x]. */
+int gr_warp_perspective(gr_ctx* ctx, const float* src, int H, int W, const double* host_M, int crop_x, int crop_y,
+                        float* dst, void* stream);
+/* apply_transformation, transforms.py:50-77, for T transforms of one already-composited triple
+ * (img, mask_lg, pert as returned by add_noise).  out = [T,3,net,net]. */
+int gr_transform_composited(gr_ctx* ctx, const float* img, const float* mask_lg, const float* pert, int H, int W,
+                            const gr_xforms* xf, int normalize, int net, float* out, void* stream);
+/* get_transformed_images, transforms.py:162-173, for C candidates x T transforms in one pass:
+ * masks/thetas = [C,3,nh,nw]; out = [C,T,3,net,net]. */
+int gr_warp_batch(gr_ctx* ctx, const float* img, int H, int W, const float* masks, const float* thetas, int C,
+                  int nh, int nw, const gr_xforms* xf, float lbd, int normalize, int net, float* out, void* stream);
+
+/* ---- victim classifiers ---------------------------------------------------------------------
+ * GTSRBNet, GTSRB/GTSRBNet.py:8-52.  tensors = 20 host pointers: weight, bias of conv1_1,
+ * conv2_1, conv2_2, conv3_1, conv3_2, conv4_1, conv4_2, fc5_1, fc6_1, fc7_1 in PyTorch layouts
+ * (OIHW / [out,in]); numel[i] is checked against the architecture. */
+int gr_model_load_gtsrb(gr_ctx* ctx, const float* const* tensors, const int64_t* numel, int n, gr_model** out);
+/* WideResNet, cifar/wideresnet.py:52-94.  tensors (host): conv1.weight; for block1..3, layer
+ * 0..n-1: bn1.{weight,bias,running_mean,running_var}, conv1.weight, bn2.{same four},
+ * conv2.weight, [convShortcut.weight when in != out planes]; then bn1.{four}, fc.weight, fc.bias. */
+int gr_model_load_wrn(gr_ctx* ctx, const float* const* tensors, const int64_t* numel, int n, int depth, int widen,
+                      int num_classes, gr_model** out);
+void gr_model_destroy(gr_model* m);
+int gr_model_num_classes(const gr_model* m);
+/* forward: x = [N,3,32,32] dev (already in the net's input range) -> logits [N,ncls] dev. */
+int gr_model_forward(gr_ctx* ctx, gr_model* m, const float* x, int N, float* logits, void* stream);
+/* predict(): torch.max(logits,1) first-maximum rule (GTSRBNet.py:66) -> preds [N] int64 dev. */
+int gr_model_predict(gr_ctx* ctx, gr_model* m, const float* x, int N, int64_t* preds, void* stream);
+
+/* ---- fused TR evaluation --------------------------------------------------------------------
+ * run_predictions(get_transformed_images(...)) for C candidates at once (utils.py:29-57):
+ * hits[c] = #{t : argmax(model(image(c,t))) == target}.  hits = int32[C] dev (overwritten).
+ * preds (int64[C*T]) and logits (float[C*T,ncls]) are optional dev outputs (NULL to skip).
+ * img_begin/img_count select the contiguous slice of the flattened image index n = c*T + t that
+ * this call (this rank) evaluates (0, C*T = everything); hits[] holds the partial counts of that
+ * slice and 0 elsewhere, so the ranks' vectors can be summed (one int32[C] all-reduce).
+ * preds/logits, when given, are full-size [C*T] arrays of which only the slice is written. */
+int gr_tr_hits(gr_ctx* ctx, gr_model* m, const float* img, int H, int W, const float* masks, const float* thetas,
+               int C, int nh, int nw, const gr_xforms* xf, float lbd, int normalize, int target, int64_t img_begin,
+               int64_t img_count, int32_t* hits, int64_t* preds, float* logits, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
