@@ -1,0 +1,176 @@
+#!/usr/bin/env python3
+"""Benchmark of the transform-robustness scoring path (BASELINE.json metric: transformed images
+classified / s, whole job).
+
+    python bench.py --gpus N --steps K --warmup W        (N>1: launched by torch.distributed.run)
+
+Workload (sharded): per GPU 512 mask candidates x 1000 seed-42 GTSRB transforms
+of the stop-sign victim (14.png, hull 14, Points/14.csv), classified by GTSRBNet in fp32 with
+seeded synthetic weights (the reference's checkpoint is not available).  N GPUs evaluate 512*N
+candidates (weak scaling): the flattened (candidate x transform) index space is split evenly over
+the ranks, each rank calls gr_tr_hits on its slice, and the int32[C] hit counts are summed by one
+all-reduce (RCCL).  A "step" is one full evaluation of all candidates; inputs are resident in HBM
+before the timed region.
+
+Besides the contract fields the JSON line carries
+  roofline      the dominant kernel (an fp32 MFMA implicit-GEMM conv instantiation): algorithmic
+                flops / HIP-event time measured inside the timed region, against 157.3 TFLOP/s
+  cpu_baseline  the CPU oracle (oracle/, a port of the reference path; the reference itself needs
+                OpenCV and cannot run) timed on a bounded sample on this box's host cores, rank 0, N=1.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "tests")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+PEAK_F32_MFMA = 157.3          # TFLOP/s, MI355X_MICROARCH.md (fp32 matrix)
+PEAK_HBM = 8000.0              # GB/s
+GTSRB_FLOPS_PER_IMAGE = 221028352
+
+
+def host_threads():
+    try:
+        n = len(os.sched_getaffinity(0))
+    except Exception:
+        n = os.cpu_count() or 1
+    return max(1, min(16, n))          # the GPU box's CPU share for one GPU is 16
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--cands-per-gpu", type=int, default=512)
+    ap.add_argument("--transforms", type=int, default=1000)
+    ap.add_argument("--chunk", type=int, default=8192)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-profile", action="store_true", help="skip the per-kernel HIP-event timing")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus N>1 must be launched with torch.distributed.run --nproc-per-node N")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    from cases import gtsrb_case
+    from graphite_amd import _hip, engine, models, synth
+
+    C_total = args.cands_per_gpu * world
+    T = args.transforms
+    case = gtsrb_case(num_xforms=T)
+    hull = case["hull"]
+    masks = synth.synth_patch_masks("bench-sweep", C_total, hull)            # hull x Bernoulli(0.5) 4x4 patches
+    thetas = ((case["tar_s"] - case["vic_s"])[None] * masks).astype(np.float32)
+    model = models.GTSRBNet()
+    model.load_state_dict(synth.gtsrb_state_dict())
+    _hip.set_chunk(args.chunk)
+    img_d, masks_d, thetas_d = _hip.to_dev(case["vic"]), _hip.to_dev(masks), _hip.to_dev(thetas)
+    xf = _hip.xform_table(case["tab"])
+    target = 1
+
+    def step():
+        return engine.tr_hits(model, img_d, masks_d, thetas_d, xf, target)
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    hits = None
+    for _ in range(args.warmup):
+        hits = step()
+    fence()
+    if not args.no_profile:
+        _hip.profile_reset()
+        _hip.profile_enable(True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        hits = step()
+    fence()
+    dt = time.perf_counter() - t0
+    prof = {}
+    if not args.no_profile:
+        _hip.profile_enable(False)
+        prof = _hip.profile_read()
+    if world > 1:
+        t = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    images = C_total * T * args.steps
+    value = images / dt
+
+    out = {
+        "metric": "transformed images classified/sec (whole job)",
+        "value": value, "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": 1000.0 * dt / max(1, args.steps), "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "config4 sweep shard: %d candidates/GPU x %d transforms, GTSRBNet fp32, stop-sign victim 244x244"
+                               % (args.cands_per_gpu, T),
+                   "candidates_total": C_total, "transforms": T, "chunk_images": args.chunk,
+                   "sharding": "contiguous slices of the (candidate x transform) index, one int32[C] all-reduce"},
+        "tr_queries_per_s": C_total * args.steps / dt,
+        "hits_checksum": int(hits.sum().item()),
+    }
+
+    if rank == 0 and prof:
+        convs = {k: v for k, v in prof.items() if k.startswith("k_conv_igemm") and v["ms"] > 0}
+        if convs:
+            name = max(convs, key=lambda k: convs[k]["ms"])
+            d = convs[name]
+            ach = d["flops"] / (d["ms"] * 1e-3) / 1e12
+            all_ms = sum(v["ms"] for v in convs.values())
+            all_fl = sum(v["flops"] for v in convs.values())
+            out["roofline"] = {"bound": "mfma", "kernel": name, "achieved": ach, "peak": PEAK_F32_MFMA, "unit": "TFLOP/s",
+                               "frac": ach / PEAK_F32_MFMA, "traffic": None,
+                               "launches": d["launches"], "avg_launch_ms": d["ms"] / d["launches"],
+                               "flops_per_launch": d["flops"] / d["launches"],
+                               "all_convs": {"achieved": all_fl / (all_ms * 1e-3) / 1e12,
+                                             "frac": all_fl / (all_ms * 1e-3) / 1e12 / PEAK_F32_MFMA, "ms": all_ms}}
+        w = prof.get("k_warp_net")
+        if w and w["ms"] > 0:
+            gbs = w["bytes"] / (w["ms"] * 1e-3) / 1e9
+            out["warp_roofline"] = {"bound": "hbm", "kernel": "k_warp_net", "achieved": gbs, "peak": PEAK_HBM, "unit": "GB/s",
+                                    "frac": gbs / PEAK_HBM, "traffic": None, "avg_launch_ms": w["ms"] / w["launches"]}
+        out["kernel_ms"] = {k: round(v["ms"], 3) for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["ms"])}
+
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        import oracle_lib as O
+        from graphite_amd import weights
+        nthr = host_threads()
+        ns = 4                                               # bounded sample: 4 candidates x T transforms
+        t1 = time.perf_counter()
+        px = O.warp_batch(case["vic"], masks[:ns], thetas[:ns], case["tab"], nthreads=nthr)
+        lg = O.gtsrb_forward(weights.gtsrb_tensor_list(synth.gtsrb_state_dict()), px.reshape(-1, 3, 32, 32), nthreads=nthr)
+        _, h_ref = O.argmax_hits(lg, T, target)
+        cdt = time.perf_counter() - t1
+        out["cpu_baseline"] = {"value": ns * T / cdt, "unit": "images/s", "cores": nthr, "kind": "port",
+                               "sample": "first %d candidates x %d transforms of the same workload (warp + GTSRBNet + argmax), %.1f s"
+                                         % (ns, T, cdt)}
+        out["parity_vs_oracle_on_sample"] = bool(np.array_equal(hits[:ns].cpu().numpy(), h_ref))
+
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -29,6 +29,9 @@ SIGNATURES = {
     "gr_last_error": (C.c_char_p, [_vp]),
     "gr_ctx_set_chunk": (_i, [_vp, _i]),
     "gr_ctx_workspace_bytes": (_i64, [_vp]),
+    "gr_profile_enable": (_i, [_vp, _i]),
+    "gr_profile_reset": (_i, [_vp]),
+    "gr_profile_read": (_i, [_vp, _i, _vp]),
     "gr_xforms_create": (_i, [_vp, _vp, _i, C.POINTER(_vp)]),
     "gr_xforms_destroy": (None, [_vp]),
     "gr_resize_linear": (_i, [_vp, _vp, _i, _i, _i, _vp, _i, _i, _vp]),
@@ -105,6 +108,29 @@ def set_chunk(images_per_chunk):
 
 def workspace_bytes():
     return int(load_library().gr_ctx_workspace_bytes(ctx()))
+
+
+class _ProfEntry(C.Structure):
+    _fields_ = [("name", C.c_char * 64), ("launches", C.c_int64), ("ms", C.c_double), ("flops", C.c_double),
+                ("bytes", C.c_double)]
+
+
+def profile_enable(on=True):
+    _check(ctx(), load_library().gr_profile_enable(ctx(), int(on)), "gr_profile_enable")
+
+
+def profile_reset():
+    _check(ctx(), load_library().gr_profile_reset(ctx()), "gr_profile_reset")
+
+
+def profile_read():
+    """{kernel name: dict(launches, ms, flops, bytes)} accumulated since the last reset."""
+    buf = (_ProfEntry * 64)()
+    n = load_library().gr_profile_read(ctx(), 64, C.cast(buf, _vp))
+    if n < 0:
+        _check(ctx(), n, "gr_profile_read")
+    return {buf[i].name.decode(): dict(launches=int(buf[i].launches), ms=buf[i].ms, flops=buf[i].flops, bytes=buf[i].bytes)
+            for i in range(n)}
 
 
 def _stream():

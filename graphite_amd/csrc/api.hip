@@ -36,6 +36,68 @@ int gr_ws_reserve(gr_ctx* ctx, size_t bytes, void* stream) {
     return GR_OK;
 }
 
+// ---------------------------------------------------------------------------------------------
+// per-kernel profiling (HIP events on the caller's stream)
+// ---------------------------------------------------------------------------------------------
+static hipEvent_t prof_event(gr_ctx* c) {
+    if (!c->prof_pool.empty()) { hipEvent_t e = c->prof_pool.back(); c->prof_pool.pop_back(); return e; }
+    hipEvent_t e = nullptr;
+    if (hipEventCreate(&e) != hipSuccess) return nullptr;
+    return e;
+}
+ProfScope::ProfScope(gr_ctx* c, const char* name, hipStream_t s, double flops, double bytes) : ctx(c), st(s) {
+    if (!c || !c->prof) return;
+    for (size_t i = 0; i < c->prof_entries.size(); i++)
+        if (c->prof_entries[i].name == name) { entry = (int)i; break; }
+    if (entry < 0) { c->prof_entries.push_back(ProfEntry()); entry = (int)c->prof_entries.size() - 1; c->prof_entries[entry].name = name; }
+    c->prof_entries[entry].launches++;
+    c->prof_entries[entry].flops += flops;
+    c->prof_entries[entry].bytes += bytes;
+    e0 = prof_event(c); e1 = prof_event(c);
+    if (e0 && e1) (void)hipEventRecord(e0, st);
+}
+ProfScope::~ProfScope() {
+    if (entry < 0 || !e0 || !e1) return;
+    (void)hipEventRecord(e1, st);
+    ctx->prof_pending.push_back({entry, e0, e1});
+}
+static void prof_drain(gr_ctx* c) {
+    for (auto& p : c->prof_pending) {
+        float ms = 0.f;
+        if (hipEventSynchronize(p.e1) == hipSuccess && hipEventElapsedTime(&ms, p.e0, p.e1) == hipSuccess)
+            c->prof_entries[p.entry].ms += ms;
+        c->prof_pool.push_back(p.e0);
+        c->prof_pool.push_back(p.e1);
+    }
+    c->prof_pending.clear();
+}
+extern "C" int gr_profile_enable(gr_ctx* ctx, int on) {
+    if (!ctx) return GR_EINVAL;
+    if (!on) prof_drain(ctx);
+    ctx->prof = on != 0;
+    return GR_OK;
+}
+extern "C" int gr_profile_reset(gr_ctx* ctx) {
+    if (!ctx) return GR_EINVAL;
+    prof_drain(ctx);
+    ctx->prof_entries.clear();
+    return GR_OK;
+}
+extern "C" int gr_profile_read(gr_ctx* ctx, int max_entries, gr_prof_entry* out) {
+    if (!ctx) return GR_EINVAL;
+    prof_drain(ctx);
+    int n = (int)ctx->prof_entries.size();
+    if (!out) return n;
+    if (n > max_entries) n = max_entries;
+    for (int i = 0; i < n; i++) {
+        const ProfEntry& e = ctx->prof_entries[i];
+        memset(&out[i], 0, sizeof(out[i]));
+        strncpy(out[i].name, e.name.c_str(), sizeof(out[i].name) - 1);
+        out[i].launches = e.launches; out[i].ms = e.ms; out[i].flops = e.flops; out[i].bytes = e.bytes;
+    }
+    return n;
+}
+
 extern "C" int gr_ctx_create(int device, gr_ctx** out) {
     if (!out) return gr_fail(nullptr, GR_EINVAL, "gr_ctx_create: out is null");
     int n = 0;
@@ -58,6 +120,8 @@ extern "C" int gr_ctx_create(int device, gr_ctx** out) {
 extern "C" void gr_ctx_destroy(gr_ctx* ctx) {
     if (!ctx) return;
     if (ctx->ws) { (void)hipDeviceSynchronize(); (void)hipFree(ctx->ws); }
+    prof_drain(ctx);
+    for (hipEvent_t e : ctx->prof_pool) (void)hipEventDestroy(e);
     delete ctx;
 }
 
@@ -192,10 +256,10 @@ extern "C" int gr_transform_composited(gr_ctx* ctx, const float* img, const floa
 extern "C" int gr_warp_batch(gr_ctx* ctx, const float* img, int H, int W, const float* masks, const float* thetas, int C, int nh,
                              int nw, const gr_xforms* xf, float lbd, int normalize, int net, float* out, void* stream) {
     NEED_CTX();
+    if (C == 0) return GR_OK;                          // empty candidate list: nothing to do (pointers may be null)
     if (!img || !masks || !thetas || !out || C < 0) return gr_fail(ctx, GR_EINVAL, "gr_warp_batch: bad arguments");
     int rc = check_frame(ctx, H, W, nh, nw, net, xf);
     if (rc) return rc;
-    if (C == 0) return GR_OK;
     hipStream_t st = (hipStream_t)stream;
     const size_t per_cand = (size_t)xf->nslots * H * W * 16;
     // candidates per pass bounded by ~2 GiB of composites

@@ -7,12 +7,27 @@
 #include <vector>
 #include "graphite_hip.h"
 
+// Optional per-kernel timing with HIP events on the caller's stream (gr_profile_*).
+struct ProfEntry { std::string name; long long launches = 0; double ms = 0, flops = 0, bytes = 0; };
+struct ProfPending { int entry; hipEvent_t e0, e1; };
+
 struct gr_ctx {
     int device = 0;
     std::string err;
     char* ws = nullptr;          // device workspace, grown on demand
     size_t ws_bytes = 0;
     int chunk = 8192;            // images per classifier chunk in gr_tr_hits
+    bool prof = false;
+    std::vector<ProfEntry> prof_entries;
+    std::vector<ProfPending> prof_pending;
+    std::vector<hipEvent_t> prof_pool;
+};
+
+// RAII: records an event pair around the launches made in its scope when profiling is on.
+struct ProfScope {
+    gr_ctx* ctx; hipStream_t st; hipEvent_t e0 = nullptr, e1 = nullptr; int entry = -1;
+    ProfScope(gr_ctx* c, const char* name, hipStream_t s, double flops, double bytes);
+    ~ProfScope();
 };
 
 // Device-side transform descriptor: inverse matrix (double), crop, blur slot, block width of the

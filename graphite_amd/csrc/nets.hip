@@ -16,6 +16,7 @@ struct Layer {
     float* w = nullptr;      // [K][NP]
     float* bias = nullptr;   // [NP]
     int Cin = 0, Cout = 0, NP = 0, KH = 1, KW = 1, stride = 1, pad = 0;
+    int CinT = 0;            // true (unpadded) input channels, for the algorithmic flop count
 };
 struct BnDev { float* scale = nullptr; float* shift = nullptr; };
 struct WrnBlock {
@@ -73,7 +74,7 @@ static int make_layer(gr_model* m, Layer* L, const float* w, const float* bias, 
         rc = upload(m, b, &L->bias);
         if (rc) return rc;
     }
-    L->Cin = CinP; L->Cout = Co; L->NP = NP; L->KH = KH; L->KW = KW; L->stride = stride; L->pad = pad;
+    L->CinT = Ci; L->Cin = CinP; L->Cout = Co; L->NP = NP; L->KH = KH; L->KW = KW; L->stride = stride; L->pad = pad;
     return GR_OK;
 }
 
@@ -300,7 +301,17 @@ static int run_conv(gr_ctx* ctx, const Layer& L, const float* in, int B, int H, 
     if (!bk || K % bk) return gr_fail(ctx, GR_EINVAL, "conv: unsupported Cin=%d K=%d", L.Cin, K);
     if (pool && ((p.Ho | p.Wo) & 1)) return gr_fail(ctx, GR_EINVAL, "conv: pooled output must be even");
     hipError_t e = hipErrorInvalidValue;
-#define GO(BK_, WM_, WN_, TM_, TN_, POOL_) e = launch_conv_igemm<BK_, WM_, WN_, TM_, TN_, POOL_>(p, st)
+    // algorithmic work of this launch: 2*M*Cout*KH*KW*Cin flops; bytes = input + weights + outputs once
+    const double flops = 2.0 * (double)M * L.Cout * L.KH * L.KW * L.CinT;
+    const double bytes = 4.0 * ((double)B * H * W * L.CinT + (double)K * L.Cout +
+                                (double)(pool ? M / 4 : M) * L.Cout * ((out_raw ? 1 : 0) + (out_act ? 1 : 0) + (res ? 1 : 0)));
+    char pname[64];
+#define GO(BK_, WM_, WN_, TM_, TN_, POOL_)                                                                        \
+    do {                                                                                                          \
+        snprintf(pname, sizeof(pname), "k_conv_igemm<%d,%d,%d,%d,%d,%d>", BK_, WM_, WN_, TM_, TN_, (int)POOL_);      \
+        ProfScope ps_(ctx, pname, st, flops, bytes);                                                              \
+        e = launch_conv_igemm<BK_, WM_, WN_, TM_, TN_, POOL_>(p, st);                                             \
+    } while (0)
     if (bn == 32) {
         if (bk == 32) { if (pool) GO(32, 4, 1, 2, 1, true); else GO(32, 4, 1, 2, 1, false); }
         else if (bk == 16 && !pool) GO(16, 4, 1, 2, 1, false);
@@ -334,7 +345,10 @@ static int gtsrb_forward(gr_ctx* ctx, gr_model* m, const float* x, int N, float*
     float* x4 = ws;
     float* A = x4 + (size_t)N * 4096;
     float* Bf = A + (size_t)N * 32768;
-    hipLaunchKernelGGL(k_input_nhwc4<true>, dim3((N * 1024 + 255) / 256), dim3(256), 0, st, x, m->c11, N, (float4*)x4);
+    {
+        ProfScope ps_(ctx, "k_input_nhwc4<conv1_1>", st, 2.0 * N * 1024 * 9, (double)N * 1024 * 28);
+        hipLaunchKernelGGL(k_input_nhwc4<true>, dim3((N * 1024 + 255) / 256), dim3(256), 0, st, x, m->c11, N, (float4*)x4);
+    }
     GR_HIP(ctx, hipGetLastError());
     int rc;
     if ((rc = run_conv(ctx, m->g[0], x4, N, 32, 32, nullptr, nullptr, A, nullptr, true, false, st))) return rc;   // conv2_1
@@ -400,6 +414,7 @@ int net_forward(gr_ctx* ctx, gr_model* m, const float* x, int N, float* logits, 
 int net_hits(gr_ctx* ctx, const float* logits, int N, int ncls, int64_t n_begin, int T, int target, int32_t* hits,
              int64_t* preds, hipStream_t st) {
     if (N <= 0) return GR_OK;
+    ProfScope ps_(ctx, "k_argmax_hits", st, 0.0, (double)N * ncls * 4);
     hipLaunchKernelGGL(k_argmax_hits, dim3((N + 255) / 256), dim3(256), 0, st, logits, N, ncls, (long long)n_begin, T,
                        target, (int*)hits, (long long*)preds);
     GR_HIP(ctx, hipGetLastError());

@@ -355,6 +355,9 @@ int px_composite(gr_ctx* ctx, const float* img, int H, int W, const float* masks
                  int nh, int nw, float lbd, const gr_xforms* xf, float* att, hipStream_t st) {
     if (ncand <= 0) return GR_OK;
     int tiles = ((W + CT - 1) / CT) * ((H + CT - 1) / CT);
+    // algorithmic bytes: image once + (mask, theta) per candidate + one RGBX composite per (candidate, blur)
+    ProfScope ps_(ctx, "k_composite", st, 0.0,
+                  12.0 * H * W + (double)ncand * (24.0 * nh * nw + 16.0 * xf->nslots * H * W));
     for (int c0 = 0; c0 < ncand; c0 += 32768) {        // gridDim.y limit
         int nc = ncand - c0 < 32768 ? ncand - c0 : 32768;
         hipLaunchKernelGGL(k_composite<false>, dim3(tiles, nc), dim3(256), 0, st, img, H, W,
@@ -378,6 +381,8 @@ int px_composite_from_pert(gr_ctx* ctx, const float* img, const float* mask_lg, 
 int px_warp_net(gr_ctx* ctx, const float* att, int H, int W, const gr_xforms* xf, int64_t n_begin, int count, int cand0,
                 int normalize, int net, float* out_chw, hipStream_t st) {
     if (count <= 0) return GR_OK;
+    // algorithmic bytes: 12 B/px written per image + 336 B of transform descriptor read
+    ProfScope ps_(ctx, "k_warp_net", st, 0.0, (double)count * (12.0 * net * net + 336.0));
     hipLaunchKernelGGL(k_warp_net, dim3(count), dim3(256), 0, st, att, H, W, xf->nslots, xf->dev, xf->T,
                        (long long)n_begin, cand0, normalize, net, out_chw);
     GR_HIP(ctx, hipGetLastError());

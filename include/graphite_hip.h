@@ -61,6 +61,21 @@ int gr_ctx_set_chunk(gr_ctx* ctx, int images_per_chunk);
 /* Bytes of device workspace currently held. */
 int64_t gr_ctx_workspace_bytes(const gr_ctx* ctx);
 
+/* ---- measurement (no counterpart in the reference, which only prints time.time() deltas,
+ * boost.py:27,55; coarse_reduction.py:76).  With profiling on, every kernel launch the library
+ * makes is bracketed by a HIP event pair on the caller's stream; gr_profile_read synchronises on
+ * the recorded events and returns, per kernel, launches, total milliseconds and the ALGORITHMIC
+ * flops / bytes of those launches (DESIGN.md states the per-unit figures). */
+typedef struct gr_prof_entry {
+    char name[64];
+    int64_t launches;
+    double ms, flops, bytes;
+} gr_prof_entry;
+int gr_profile_enable(gr_ctx* ctx, int on);
+int gr_profile_reset(gr_ctx* ctx);
+/* Returns the number of entries written (out == NULL: the number available). */
+int gr_profile_read(gr_ctx* ctx, int max_entries, gr_prof_entry* out);
+
 /* ---- transform table ------------------------------------------------------------------------
  * Uploads T descriptors once (inverse matrices are formed in double on the host, as
  * cv2.warpPerspective does before warping); reused by every call of an attack. */
