@@ -23,11 +23,29 @@ def shard_range(total, rank, world):
 
 
 def allreduce_hits(hits, group=None):
-    """Sum the per-candidate partial counts over the ranks (no-op without torch.distributed)."""
+    """Sum the per-candidate partial counts over the ranks (no-op without torch.distributed).
+    With the nccl (= RCCL) backend the int32[C] vector is reduced in place on the GPU over xGMI;
+    with gloo (CPU rehearsal / tests) it takes a round trip through host memory."""
     import torch.distributed as dist
     if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
-        dist.all_reduce(hits, op=dist.ReduceOp.SUM, group=group)
+        if dist.get_backend(group) == "gloo" and hits.is_cuda:
+            h = hits.cpu()
+            dist.all_reduce(h, op=dist.ReduceOp.SUM, group=group)
+            hits.copy_(h)
+        else:
+            dist.all_reduce(hits, op=dist.ReduceOp.SUM, group=group)
     return hits
+
+
+def sharded_hits(eval_slice, total, distributed=True, group=None):
+    """Run `eval_slice(begin, count) -> int32[C]` (partial counts of images [begin, begin+count) of the
+    flattened candidate x transform index) on this rank's slice and sum over the ranks."""
+    import torch.distributed as dist
+    sharded = distributed and dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+    if not sharded:
+        return eval_slice(0, total)
+    begin, count = shard_range(total, dist.get_rank(group), dist.get_world_size(group))
+    return allreduce_hits(eval_slice(begin, count), group)
 
 
 def _as_table(transforms, w, h, pt_file):
@@ -55,17 +73,17 @@ def tr_hits(model, image, masks, thetas, transforms, target, pt_file='inputs/GTS
         m, t = m[None], t[None]
     xf = _hip.xform_table(tab)
     total = m.shape[0] * xf.T
-    begin, count = 0, total
-    import torch.distributed as dist
-    sharded = distributed and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
-    if sharded:
-        begin, count = shard_range(total, dist.get_rank(), dist.get_world_size())
-    hits, preds, _ = _hip.tr_hits_dev(hip_model, img, m, t, xf, float(lbd), model_type == 'GTSRB', int(target),
-                                      begin, count, want_preds=return_preds)
-    if sharded:
-        allreduce_hits(hits)
+    keep = {}
+
+    def eval_slice(begin, count):
+        hits, preds, _ = _hip.tr_hits_dev(hip_model, img, m, t, xf, float(lbd), model_type == 'GTSRB', int(target),
+                                          begin, count, want_preds=return_preds)
+        keep["preds"] = preds
+        return hits
+
+    hits = sharded_hits(eval_slice, total, distributed)
     if return_preds:
-        return hits, preds.view(m.shape[0], xf.T)
+        return hits, keep["preds"].view(m.shape[0], xf.T)
     return hits
 
 
