@@ -296,7 +296,7 @@ def golden_binary_search():
         json.dump(rows, f)
 
 
-if __name__ == "__main__":
+if __name__ == "__main__" and "--drivers" not in sys.argv:
     xf = golden_xforms()
     golden_homography(xf)
     golden_score()
@@ -304,3 +304,105 @@ if __name__ == "__main__":
     golden_binary_search()
     golden_nets()
     print("golden fixtures written to", HERE)
+
+
+# ----------------------------------------------------------------- (7) search-driver control flow
+def golden_drivers():
+    """Run the reference's generate_mask / boost / get_coarse_reduced_mask with the transform+classify
+    pair replaced by tests/fake_tr.FakeTR (a deterministic function of the exact mask/theta bytes).
+    cv2.resize -- which these drivers call on 32x32 / 244x244 float images -- is served by the CPU
+    oracle's resize (the same one the tests give our drivers), so what is pinned is the reference's
+    HOST LOGIC: decisions, masks, thetas, query counts, RNG consumption."""
+    import hashlib
+    sys.path.insert(0, os.path.join(REPO, "tests"))
+    import oracle_lib as O
+    from fake_tr import FakeTR
+    from graphite_amd.imageio import load_image_chw
+    import generate_mask as ref_gm
+    import boost as ref_boost
+
+    def cv_resize(a, dsize):
+        chw = np.ascontiguousarray(np.transpose(np.asarray(a, np.float32), (2, 0, 1)))
+        return np.ascontiguousarray(np.transpose(O.resize_linear(chw, dsize[1], dsize[0]), (1, 2, 0)))
+
+    cv2.resize = cv_resize
+    cv2.cvtColor = lambda a, code: a
+    cv2.COLOR_RGB2BGR = 0
+
+    vic = torch.from_numpy(load_image_chw(os.path.join(INP, "GTSRB/images/14.png")))
+    tar = torch.from_numpy(load_image_chw(os.path.join(INP, "GTSRB/images/1.png")))
+    hull = torch.from_numpy((load_image_chw(os.path.join(INP, "GTSRB/Hulls/14.png")) * 255 > 128).astype(np.float32))
+    vic_s = torch.from_numpy(O.resize_linear(vic.numpy(), 32, 32))
+    tar_s = torch.from_numpy(O.resize_linear(tar.numpy(), 32, 32))
+    obj = float(hull.sum() / 3)
+    ref_dir = (tar_s - vic_s) * hull
+
+    def install(mod, fake):
+        mod.get_transformed_images = lambda img, mask, xf, lbd, theta, pt_file, net_size=32, model_type='GTSRB': (mask.clone(), theta.clone())
+        mod.run_predictions = lambda model, imgs, lbl_v, lbl_t=None: fake.err(imgs[0], imgs[1])
+
+    def digest(t):
+        return hashlib.sha256(np.ascontiguousarray(t.numpy()).tobytes()).hexdigest()
+
+    class _M:
+        def predict(self, x):
+            return 0
+
+    rows = []
+    pt = os.path.join(INP, "GTSRB/Points/14.csv")
+    for name, T, heat, coarse_mode, tr_lo, tr_hi, max_mask, sharp, mid in (
+        ("target_binary", 100, "Target", "binary", 0.65, 0.85, -1, 6.0, 0.35),
+        ("target_linear", 50, "Target", "linear", 0.5, 0.8, -1, 6.0, 0.35),
+        ("random_binary", 100, "Random", "binary", 0.65, 0.85, -1, 10.0, 0.5),
+        ("target_none_maxmask", 40, "Target", "none", 0.4, 0.6, 300, 6.0, 0.2),
+        ("victim_binary", 30, "Victim", "binary", 0.3, 0.6, -1, 4.0, 0.3),
+    ):
+        fake = FakeTR(T, obj, ref_dir, sharp, mid)
+        install(ref_gm, fake)
+        install(ref_coarse, fake)
+        ref_gm.get_coarse_reduced_mask = ref_coarse.get_coarse_reduced_mask
+        sys.argv = ["main.py", "--coarse_mode", coarse_mode]
+        np.random.seed(42); torch.manual_seed(42)
+        import random as _r
+        _r.seed(42)
+        attacked, qc, best_mask, nbits, best_tr = ref_gm.generate_mask(
+            _M(), vic_s, vic, 14, hull.clone(), tar_s, tar, 1, pt, "score.py", heat, 1 - tr_hi, 1 - tr_lo,
+            num_xforms=T, net_size=32, model_type='GTSRB', patch_size=4, heatmap_file=None, heatmap_out_path=None,
+            max_mask_size=max_mask, init_theta=None)
+        rows.append({"kind": "generate_mask", "name": name, "T": T, "heatmap": heat, "coarse_mode": coarse_mode,
+                     "tr_lo": tr_lo, "tr_hi": tr_hi, "max_mask_size": max_mask, "sharp": sharp, "mid": mid,
+                     "query_count": int(qc), "nbits": float(nbits), "best_tr": float(best_tr),
+                     "best_mask": best_mask.numpy()[0].astype(np.uint8).tolist(), "attacked_sha": digest(attacked),
+                     "fake_calls": fake.calls, "np_random_next": float(np.random.uniform()),
+                     "py_random_next": _r.random()})
+        print(name, "queries", qc, "bits", nbits, "tr", best_tr, "calls", fake.calls)
+
+    small_mask = torch.zeros(3, 32, 32)
+    small_mask[:, 10:22, 8:24] = 1
+    small_mask = small_mask * hull
+    for name, T, bt, iters, budget, use_init, model_type in (
+        ("rgf_plain", 100, False, 1000, 200, False, "GTSRB"),
+        ("rgf_bt", 50, True, 6, 200, False, "GTSRB"),
+        ("rgf_init_theta_cifar", 20, False, 3, 200, True, "CIFAR"),
+    ):
+        fake = FakeTR(T, obj, ref_dir, 6.0, 0.1)
+        install(ref_boost, fake)
+        ref_boost.add_noise = ref_transforms.add_noise
+        ref_boost.convert2Network = lambda *a, **k: torch.zeros(3, 32, 32)
+        np.random.seed(42); torch.manual_seed(42)
+        init_theta = (tar_s - vic_s) * 0.5 if use_init else None
+        adv, tr, perturb, queries, best_theta, adv_small = ref_boost.boost(
+            _M(), vic, 14, small_mask, tar_s, 1, beta=1, iterations=iters, pt_file=pt, num_xforms=T, net_size=32,
+            model_type=model_type, bt=bt, budget_factor=budget, init_theta=init_theta)
+        rows.append({"kind": "boost", "name": name, "T": T, "bt": bt, "iterations": iters, "budget_factor": budget,
+                     "use_init": use_init, "model_type": model_type, "tr": float(tr), "queries": int(queries),
+                     "best_theta_sha": digest(best_theta), "adv_sha": digest(adv), "perturb_sha": digest(perturb),
+                     "adv_small_sha": digest(adv_small), "fake_calls": fake.calls,
+                     "torch_random_next": float(torch.rand(1)), "np_random_next": float(np.random.uniform())})
+        print(name, "tr", tr, "queries", queries, "calls", fake.calls)
+    with open(os.path.join(HERE, "drivers.json"), "w") as f:
+        json.dump(rows, f)
+
+
+if __name__ == "__main__" and "--drivers" in sys.argv:
+    golden_drivers()

@@ -1,0 +1,124 @@
+"""Search drivers (boost / generate_mask / coarse_reduction) vs the REFERENCE'S OWN drivers.
+
+tests/golden/drivers.json was produced by running the reference's generate_mask.py / boost.py /
+coarse_reduction.py with the transform+classify pair replaced by tests/fake_tr.FakeTR (see
+make_golden.py::golden_drivers).  Here our batched / speculative drivers run with the same fake
+evaluator; decisions, masks, thetas, reported query counts and RNG consumption must be identical,
+while the number of LAUNCHES must be far smaller (that is the point of batching).
+"""
+import hashlib
+import json
+import os
+import random
+
+import numpy as np
+import pytest
+import torch
+
+from cases import GOLD, INP
+from fake_tr import FakeEvaluator, FakeTR
+from graphite_amd import boost as gboost
+from graphite_amd import coarse_reduction as gcoarse
+from graphite_amd import generate_mask as ggm
+from graphite_amd import parsearguments
+from graphite_amd.imageio import load_image_chw
+
+ROWS = json.load(open(os.path.join(GOLD, "drivers.json")))
+PT = os.path.join(INP, "GTSRB/Points/14.csv")
+
+
+def _digest(t):
+    return hashlib.sha256(np.ascontiguousarray(t.numpy()).tobytes()).hexdigest()
+
+
+@pytest.fixture(scope="module")
+def scene(oracle):
+    vic = torch.from_numpy(load_image_chw(os.path.join(INP, "GTSRB/images/14.png")))
+    tar = torch.from_numpy(load_image_chw(os.path.join(INP, "GTSRB/images/1.png")))
+    hull = torch.from_numpy((load_image_chw(os.path.join(INP, "GTSRB/Hulls/14.png")) * 255 > 128).astype(np.float32))
+    vic_s = torch.from_numpy(oracle.resize_linear(vic.numpy(), 32, 32))
+    tar_s = torch.from_numpy(oracle.resize_linear(tar.numpy(), 32, 32))
+    return dict(vic=vic, tar=tar, hull=hull, vic_s=vic_s, tar_s=tar_s, obj=float(hull.sum() / 3),
+                ref_dir=(tar_s - vic_s) * hull)
+
+
+@pytest.mark.parametrize("row", [r for r in ROWS if r["kind"] == "generate_mask"], ids=lambda r: r["name"])
+def test_generate_mask_matches_reference_driver(row, scene, oracle):
+    fake = FakeTR(row["T"], scene["obj"], scene["ref_dir"], row["sharp"], row["mid"])
+    ev = FakeEvaluator(fake, oracle)
+    args = parsearguments.getarguments(["--coarse_mode", row["coarse_mode"]])
+    np.random.seed(42); torch.manual_seed(42); random.seed(42)
+    attacked, qc, best_mask, nbits, best_tr = ggm.generate_mask(
+        None, scene["vic_s"], scene["vic"], 14, scene["hull"].clone(), scene["tar_s"], scene["tar"], 1, PT, "score.py",
+        row["heatmap"], 1 - row["tr_hi"], 1 - row["tr_lo"], num_xforms=row["T"], net_size=32, model_type='GTSRB',
+        patch_size=4, max_mask_size=row["max_mask_size"], _evaluator=ev, _args=args)
+    assert int(qc) == row["query_count"]
+    assert float(nbits) == row["nbits"] and float(best_tr) == row["best_tr"]
+    assert best_mask.numpy()[0].astype(np.uint8).tolist() == row["best_mask"]
+    assert torch.equal(best_mask[0], best_mask[1]) and torch.equal(best_mask[0], best_mask[2])
+    assert _digest(attacked) == row["attacked_sha"]
+    assert float(np.random.uniform()) == row["np_random_next"] and random.random() == row["py_random_next"]
+    # batching: the reference made `fake_calls` one-candidate round trips; we made far fewer launches,
+    # and speculation evaluated at most a bounded number of extra candidates
+    assert ev.launches < row["fake_calls"] / 3
+    assert ev.evaluated >= row["fake_calls"]
+    print(row["name"], "reference evals", row["fake_calls"], "our launches", ev.launches, "our evals", ev.evaluated)
+
+
+@pytest.mark.parametrize("row", [r for r in ROWS if r["kind"] == "boost"], ids=lambda r: r["name"])
+def test_boost_matches_reference_driver(row, scene, oracle):
+    fake = FakeTR(row["T"], scene["obj"], scene["ref_dir"], 6.0, 0.1)
+    ev = FakeEvaluator(fake, oracle)
+    small_mask = torch.zeros(3, 32, 32)
+    small_mask[:, 10:22, 8:24] = 1
+    small_mask = small_mask * scene["hull"]
+    init_theta = (scene["tar_s"] - scene["vic_s"]) * 0.5 if row["use_init"] else None
+    np.random.seed(42); torch.manual_seed(42)
+    adv, tr, perturb, queries, best_theta, adv_small = gboost.boost(
+        None, scene["vic"], 14, small_mask, scene["tar_s"], 1, beta=1, iterations=row["iterations"], pt_file=PT,
+        num_xforms=row["T"], net_size=32, model_type=row["model_type"], bt=row["bt"], budget_factor=row["budget_factor"],
+        init_theta=init_theta, _evaluator=ev)
+    assert float(tr) == row["tr"] and int(queries) == row["queries"]
+    assert _digest(best_theta) == row["best_theta_sha"]
+    assert _digest(adv) == row["adv_sha"] and _digest(perturb) == row["perturb_sha"]
+    assert _digest(adv_small) == row["adv_small_sha"]
+    assert float(torch.rand(1)) == row["torch_random_next"] and float(np.random.uniform()) == row["np_random_next"]
+    assert ev.evaluated == row["fake_calls"]              # no speculation in boost: exactly the reference's evaluations
+    assert ev.launches < row["fake_calls"]                # 10 directions per launch
+
+
+def test_binary_search_replay_table(oracle):
+    """perform_binary_coarse_reduction vs the reference on synthetic monotone / non-monotone TR tables."""
+    rows = json.load(open(os.path.join(GOLD, "binary_search.json")))
+    for r in rows:
+        n, table = r["n"], r["table"]
+        patches = []
+        for i in range(n):
+            p = torch.zeros(3, 32, 32)
+            p[:, (i // 8) * 4:(i // 8) * 4 + 4, (i % 8) * 4:(i % 8) * 4 + 4] = 1
+            patches.append(p)
+        calls = []
+
+        class Ev:
+            def error(self, mask, theta):
+                piv = int(round(float(mask.sum()) / 3 / 16))
+                calls.append(piv)
+                return 1.0 - table[piv], 100
+
+        z = torch.zeros(3, 32, 32)
+        pivot, best_mask, best_tr, q = gcoarse.perform_binary_coarse_reduction(
+            patches, r["err_threshold"], 14, 1, z, z, torch.zeros(3, 244, 244), None, [None] * 100, torch.ones(3, 32, 32),
+            None, 32, _evaluator=Ev())
+        assert (int(pivot), float(best_tr), int(q), float(best_mask.sum() / 3)) == (r["pivot"], r["best_tr"], r["queries"],
+                                                                                    r["mask_bits"])
+        assert calls == r["calls"]
+
+
+def test_parsearguments_defaults_and_derived():
+    a = parsearguments.getarguments([])
+    assert (a.victim_id, a.target_id, a.coarse_mode, a.heatmap, a.seed) == ('14', '1', 'binary', 'Target', 42)
+    assert (a.boost_transforms, a.mask_transforms, a.lbl_v, a.lbl_t) == (100, 100, 14, 1)
+    assert a.coarse_error == 0.5 and a.reduce_error == 0.75
+    a = parsearguments.getarguments("-v 14 -t 27 --tr_lo 0.65 --tr_hi 0.85 -b 100 -m 100 --coarse_mode=binary --junk 1".split())
+    assert a.lbl_t == 27 and abs(a.coarse_error - 0.15) < 1e-12 and abs(a.reduce_error - 0.35) < 1e-12
+    assert a.img_v == 'inputs/GTSRB/images/14.png' and a.mask == 'inputs/GTSRB/Hulls/14.png'
