@@ -8,7 +8,7 @@ the reference step by step.
 """
 import torch
 
-from .evaluator import TREvaluator
+from .evaluator import TREvaluator, make_evaluator
 from .transforms import get_transform_params, convert2Network
 
 
@@ -16,7 +16,7 @@ def boost(model, x0_large, y0, mask, target_example, target=None, beta=1, iterat
           num_xforms=1000, net_size=32, model_type='GTSRB', goal=None, eta=500, bt=False, budget_factor=200,
           init_theta=None, square_mask=False, early_boost_exit=False, _evaluator=None):
     xforms = get_transform_params(num_xforms, model_type)
-    ev = _evaluator or TREvaluator(model, x0_large, xforms, pt_file, model_type, y0, target)
+    ev = make_evaluator(_evaluator, model, x0_large, xforms, pt_file, model_type, y0, target)
     query_count = 0
     x0 = ev.resize(x0_large, mask.size()[1], mask.size()[2])
     theta = init_theta * mask if init_theta is not None else (target_example - x0) * mask

@@ -13,7 +13,7 @@ import time
 
 import torch
 
-from .evaluator import TREvaluator
+from .evaluator import TREvaluator, make_evaluator
 
 
 def _union(best_mask, patch):
@@ -31,7 +31,7 @@ def get_coarse_reduced_mask(start_mask, object_size, patches, indices, img_v, im
                             _evaluator=None):
     if args is not None:
         coarse_red_mode = args.coarse_mode
-    ev = _evaluator or TREvaluator(model, img_v, xforms, pt_file, model_type, lbl_v, lbl_t)
+    ev = make_evaluator(_evaluator, model, img_v, xforms, pt_file, model_type, lbl_v, lbl_t)
     q = 0
     img_v_small = ev.resize(img_v, start_mask.size()[1], start_mask.size()[2])
     if img_t.size()[1] != img_v_small.size()[1] or img_t.size()[2] != img_v_small.size()[2]:
@@ -61,7 +61,7 @@ def get_coarse_reduced_mask(start_mask, object_size, patches, indices, img_v, im
 
 def perform_linear_coarse_reduction(patches, err_threshold, lbl_v, lbl_t, img_t_small, img_v_small, img_v, model, xforms,
                                     start_mask, pt_file, net_size, model_type='GTSRB', init_theta=None, _evaluator=None):
-    ev = _evaluator or TREvaluator(model, img_v, xforms, pt_file, model_type, lbl_v, lbl_t)
+    ev = make_evaluator(_evaluator, model, img_v, xforms, pt_file, model_type, lbl_v, lbl_t)
     best_mask, best_tr, tot = torch.zeros(start_mask.size()), 0, 0
     j = 0
     for j in range(len(patches)):
@@ -79,7 +79,7 @@ def perform_linear_coarse_reduction(patches, err_threshold, lbl_v, lbl_t, img_t_
 def perform_binary_coarse_reduction(patches, err_threshold, lbl_v, lbl_t, img_t_small, img_v_small, img_v, model, xforms,
                                     start_mask, pt_file, net_size, direction="forward", model_type='GTSRB',
                                     init_theta=None, _evaluator=None):
-    ev = _evaluator or TREvaluator(model, img_v, xforms, pt_file, model_type, lbl_v, lbl_t)
+    ev = make_evaluator(_evaluator, model, img_v, xforms, pt_file, model_type, lbl_v, lbl_t)
     tot = 0
     # prefix unions are built incrementally (the reference rebuilds them from scratch per pivot, :128-136)
     prefix = {0: torch.zeros(start_mask.size())}

@@ -55,6 +55,11 @@ class TREvaluator:
     def error(self, mask, theta):
         return self.errors(mask[None], theta[None])[0]
 
+    def swapped(self, image, label, target):
+        """Same model / transforms with another base image and labels (the 'Victim' heatmap,
+        generate_mask.py:262-263, transforms the TARGET image and counts VICTIM-label hits)."""
+        return TREvaluator(self.model, image, self.transforms, self.pt_file, self.model_type, label, target, self.lbd)
+
     # ---- image helpers (cv2.resize / add_noise in the reference's drivers) ----------------------
     @staticmethod
     def resize(t, h, w):
@@ -65,3 +70,13 @@ class TREvaluator:
     def add_noise(image, mask, lbd, theta, clip=True):
         from .transforms import add_noise
         return add_noise(image, mask, lbd, theta, clip=clip)
+
+
+def make_evaluator(spec, model, image, transforms, pt_file, model_type, label, target):
+    """`spec` is None (GPU evaluator), an evaluator object, or a factory with TREvaluator's signature
+    (tests use a factory to bind an oracle-backed evaluator to the transform list drawn inside a driver)."""
+    if spec is None:
+        return TREvaluator(model, image, transforms, pt_file, model_type, label, target)
+    if hasattr(spec, "errors") or hasattr(spec, "error"):
+        return spec
+    return spec(model, image, transforms, pt_file, model_type, label, target)

@@ -23,7 +23,7 @@ import torch
 
 from . import parsearguments
 from .coarse_reduction import get_coarse_reduced_mask
-from .evaluator import TREvaluator
+from .evaluator import TREvaluator, make_evaluator
 from .transforms import get_transform_params
 
 scoremod = None
@@ -49,7 +49,7 @@ def generate_mask(model, img_v_small, img_v, lbl_v, mask, img_t_small, img_t, lb
 
     print("Calculating Heatmap...")
     xforms = get_transform_params(num_xforms, model_type)
-    ev = _evaluator or TREvaluator(model, img_v, xforms, pt_file, model_type, lbl_v, lbl_t)
+    ev = make_evaluator(_evaluator, model, img_v, xforms, pt_file, model_type, lbl_v, lbl_t)
     query_count = 0
     object_size = mask.sum() / 3
     patch = torch.ones((3, patch_size, patch_size))
@@ -125,7 +125,7 @@ def generate_mask(model, img_v_small, img_v, lbl_v, mask, img_t_small, img_t, lb
 
 def get_heatmap(start_mask, patches, indices, img_v, img_t, lbl_v, lbl_t, model, xforms, pt_file, net_size, init_tr=0.5,
                 plot=False, model_type='GTSRB', init_theta=None, _evaluator=None):
-    ev = _evaluator or TREvaluator(model, img_v, xforms, pt_file, model_type, lbl_v, lbl_t)
+    ev = make_evaluator(_evaluator, model, img_v, xforms, pt_file, model_type, lbl_v, lbl_t)
     img_v_small = ev.resize(img_v, start_mask.size()[1], start_mask.size()[2])
     if img_t.size()[1] != start_mask.size()[1] or img_t.size()[2] != start_mask.size()[2]:
         img_t = ev.resize(img_t, start_mask.size()[1], start_mask.size()[2])
@@ -141,7 +141,7 @@ def get_heatmap(start_mask, patches, indices, img_v, img_t, lbl_v, lbl_t, model,
 def get_fine_reduced_mask(start_mask, object_size, patches, indices, img_v, img_t, lbl_v, lbl_t, model, xforms, pt_file,
                           net_size, err_threshold=0.75, HEATMAP_MODE=None, scoremod=None, lbd=5, max_mask_size=-1,
                           model_type='GTSRB', init_theta=None, _evaluator=None):
-    ev = _evaluator or TREvaluator(model, img_v, xforms, pt_file, model_type, lbl_v, lbl_t)
+    ev = make_evaluator(_evaluator, model, img_v, xforms, pt_file, model_type, lbl_v, lbl_t)
     reduction_query_ct = 0
     img_v_small = ev.resize(img_v, start_mask.size()[1], start_mask.size()[2])
     if img_t.size()[1] != img_v_small.size()[1] or img_t.size()[2] != img_v_small.size()[2]:
