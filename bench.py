@@ -64,10 +64,17 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("--gpus N>1 must be launched with torch.distributed.run --nproc-per-node N")
-    torch.cuda.set_device(local_rank)
+    # Rehearsal knobs for a 1-GPU box (never set by the driver): all ranks on device 0, gloo instead of RCCL.
+    one_device = os.environ.get("GRAPHITE_BENCH_ONE_DEVICE") == "1"
+    backend = os.environ.get("GRAPHITE_BENCH_BACKEND", "nccl")
+    dev = 0 if one_device else local_rank
+    torch.cuda.set_device(dev)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev))
+        else:
+            dist.init_process_group(backend)
 
     from cases import gtsrb_case
     from graphite_amd import _hip, engine, models, synth
@@ -111,7 +118,7 @@ def main():
         _hip.profile_enable(False)
         prof = _hip.profile_read()
     if world > 1:
-        t = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        t = torch.tensor([dt], device="cuda" if backend == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     images = C_total * T * args.steps
@@ -131,7 +138,7 @@ def main():
     }
 
     if rank == 0 and prof:
-        convs = {k: v for k, v in prof.items() if k.startswith("k_conv_igemm") and v["ms"] > 0}
+        convs = {k: v for k, v in prof.items() if k.startswith("k_conv") and v["ms"] > 0}
         if convs:
             name = max(convs, key=lambda k: convs[k]["ms"])
             d = convs[name]
@@ -155,7 +162,7 @@ def main():
         import oracle_lib as O
         from graphite_amd import weights
         nthr = host_threads()
-        ns = 4                                               # bounded sample: 4 candidates x T transforms
+        ns = min(64, C_total)                                # bounded sample: 64 candidates x T transforms (~15 s of CPU)
         t1 = time.perf_counter()
         px = O.warp_batch(case["vic"], masks[:ns], thetas[:ns], case["tab"], nthreads=nthr)
         lg = O.gtsrb_forward(weights.gtsrb_tensor_list(synth.gtsrb_state_dict()), px.reshape(-1, 3, 32, 32), nthreads=nthr)

@@ -5,6 +5,8 @@
 // target-hit count is a wavefront-reduction kernel (utils.py:51-52).
 #include "common.h"
 #include "conv_igemm.h"
+#include "conv_halo.h"
+#include <stdlib.h>
 #include <math.h>
 #include <stdarg.h>
 #include <string.h>
@@ -341,6 +343,70 @@ static size_t per_image_floats(const gr_model* m) {
 }
 size_t net_workspace_bytes(const gr_model* m, int N) { return gr_align(per_image_floats(m) * sizeof(float) * (size_t)N); }
 
+// GRAPHITE_HALO_VARIANT="l:v,l:v" picks a tiling variant per layer (tuning runs); default 0.
+static int halo_variant(int layer) {
+    static int tab[8] = {-1, 0, 0, 0, 0, 0, 0, 0};
+    if (tab[0] < 0) {
+        for (int i = 0; i < 8; i++) tab[i] = 0;
+        const char* e = getenv("GRAPHITE_HALO_VARIANT");
+        while (e && *e) {
+            int l = -1, v = 0;
+            if (sscanf(e, "%d:%d", &l, &v) == 2 && l >= 0 && l < 8 && v >= 0 && v < 8) tab[l] = v;
+            e = strchr(e, ',');
+            if (e) e++;
+        }
+    }
+    return tab[layer];
+}
+
+// GTSRBNet's 5x5 convs through the halo-tile kernel (conv_halo.h).  layer = index into gr_model::g.
+static int run_gtsrb_halo(gr_ctx* ctx, const Layer& L, int layer, const float* in, int B, int H, float* out, hipStream_t st) {
+    HaloParams p;
+    p.in = in; p.wgt = L.w; p.bias = L.bias; p.out = out; p.B = B; p.H = H; p.W = H; p.Cout = L.Cout; p.relu = 1;
+    const bool pool = layer == 1 || layer == 3 || layer == 5;
+    const double M = (double)B * H * H;
+    const double flops = 2.0 * M * L.Cout * 25 * L.CinT;
+    const double bytes = 4.0 * (M * L.CinT + 25.0 * L.CinT * L.Cout + (pool ? M / 4 : M) * L.Cout);
+    char pname[64];
+    snprintf(pname, sizeof(pname), "k_conv_halo<conv%d_%d>", 2 + layer / 2, 1 + layer % 2);
+    ProfScope ps_(ctx, pname, st, flops, bytes);
+    hipError_t e = hipErrorInvalidValue;
+    const int v = halo_variant(layer);
+    //                            CIN CPH KH KW  PS  TH  TW NIMG WM WN TM TN  KU   NP  POOL
+#define HL(...) e = launch_conv_halo<__VA_ARGS__>(p, st)
+    switch (layer * 8 + v) {            // variant 0 of each layer = the fastest measured (profiles/r01_tune_*.log)
+    case 0 * 8 + 0: HL( 20,  4, 5, 1,   4, 16, 32, 1,  4, 1, 4, 1,  5,  32, false, 0); break;   // conv2_1
+    case 0 * 8 + 1: HL( 20,  4, 5, 1,   4,  8, 32, 1,  4, 1, 2, 1,  5,  32, false, 1); break;
+    case 0 * 8 + 2: HL( 20,  4, 5, 1,   4,  8, 32, 1,  4, 1, 2, 1,  5,  32, false, 0); break;
+    case 1 * 8 + 0: HL( 32, 32, 5, 5,  33,  8, 32, 1,  4, 1, 2, 1, 16,  32, true , 0); break;   // conv2_2
+    case 1 * 8 + 1: HL( 32, 32, 5, 5,  33,  8, 32, 1,  4, 1, 2, 1,  8,  32, true , 0); break;
+    case 1 * 8 + 2: HL( 32, 32, 5, 5,  33, 16, 32, 1,  4, 1, 4, 1,  8,  32, true , 0); break;
+    case 1 * 8 + 3: HL( 32, 32, 5, 5,  33, 16, 32, 1,  8, 1, 2, 1,  8,  32, true , 0); break;
+    case 2 * 8 + 0: HL( 32, 32, 5, 5,  33, 16, 16, 1,  2, 2, 4, 1,  8,  64, false, 0); break;   // conv3_1
+    case 2 * 8 + 1: HL( 32, 32, 5, 5,  33, 16, 16, 1,  2, 2, 4, 1, 16,  64, false, 0); break;
+    case 2 * 8 + 2: HL( 32, 32, 5, 5,  33, 16, 16, 1,  4, 1, 2, 2,  8,  64, false, 0); break;
+    case 3 * 8 + 0: HL( 64, 64, 5, 5,  65,  8, 16, 1,  2, 2, 2, 1, 16,  64, true , 0); break;   // conv3_2
+    case 3 * 8 + 1: HL( 64, 64, 5, 5,  65,  8, 16, 1,  2, 2, 2, 1,  8,  64, true , 0); break;
+    case 3 * 8 + 2: HL( 64, 64, 5, 5,  65,  8, 16, 1,  2, 2, 2, 1, 32,  64, true , 0); break;
+    case 4 * 8 + 0: HL( 64, 64, 5, 5,  65,  8,  8, 2,  1, 4, 4, 1, 16, 128, false, 0); break;   // conv4_1
+    case 4 * 8 + 1: HL( 64, 64, 5, 5,  65,  8,  8, 2,  2, 2, 2, 2,  8, 128, false, 0); break;
+    case 4 * 8 + 2: HL( 64, 64, 5, 5,  65,  8,  8, 2,  1, 4, 4, 1,  8, 128, false, 0); break;
+    case 5 * 8 + 0: HL(128,128, 5, 5, 129,  8,  8, 1,  1, 4, 2, 1, 16, 128, true , 0); break;   // conv4_2
+    case 5 * 8 + 1: HL(128,128, 5, 5, 129,  8,  8, 1,  1, 4, 2, 1,  8, 128, true , 0); break;
+    case 5 * 8 + 2: HL(128,128, 5, 5, 129,  8,  8, 1,  1, 4, 2, 1, 32, 128, true , 0); break;
+    default: return gr_fail(ctx, GR_EINVAL, "conv_halo: no variant %d for layer %d", v, layer);
+    }
+#undef HL
+    if (e != hipSuccess) return gr_fail(ctx, GR_EHIP, "conv_halo launch (layer %d): %s", layer, hipGetErrorString(e));
+    return GR_OK;
+}
+
+static bool use_igemm_convs() {      // GRAPHITE_CONV=igemm selects the im2col-chunk kernels for A/B runs
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("GRAPHITE_CONV"); v = (e && strcmp(e, "igemm") == 0) ? 1 : 0; }
+    return v == 1;
+}
+
 static int gtsrb_forward(gr_ctx* ctx, gr_model* m, const float* x, int N, float* logits, float* ws, hipStream_t st) {
     float* x4 = ws;
     float* A = x4 + (size_t)N * 4096;
@@ -351,6 +417,17 @@ static int gtsrb_forward(gr_ctx* ctx, gr_model* m, const float* x, int N, float*
     }
     GR_HIP(ctx, hipGetLastError());
     int rc;
+    if (!use_igemm_convs()) {
+        if ((rc = run_gtsrb_halo(ctx, m->g[0], 0, x4, N, 32, A, st))) return rc;
+        if ((rc = run_gtsrb_halo(ctx, m->g[1], 1, A, N, 32, Bf, st))) return rc;
+        if ((rc = run_gtsrb_halo(ctx, m->g[2], 2, Bf, N, 16, A, st))) return rc;
+        if ((rc = run_gtsrb_halo(ctx, m->g[3], 3, A, N, 16, Bf, st))) return rc;
+        if ((rc = run_gtsrb_halo(ctx, m->g[4], 4, Bf, N, 8, A, st))) return rc;
+        if ((rc = run_gtsrb_halo(ctx, m->g[5], 5, A, N, 8, Bf, st))) return rc;
+        if ((rc = run_conv(ctx, m->g[6], Bf, N, 1, 1, nullptr, nullptr, A, nullptr, true, false, st))) return rc;     // fc5
+        if ((rc = run_conv(ctx, m->g[7], A, N, 1, 1, nullptr, nullptr, Bf, nullptr, true, false, st))) return rc;     // fc6
+        return run_conv(ctx, m->g[8], Bf, N, 1, 1, nullptr, nullptr, logits, nullptr, false, false, st);             // fc7
+    }
     if ((rc = run_conv(ctx, m->g[0], x4, N, 32, 32, nullptr, nullptr, A, nullptr, true, false, st))) return rc;   // conv2_1
     if ((rc = run_conv(ctx, m->g[1], A, N, 32, 32, nullptr, nullptr, Bf, nullptr, true, true, st))) return rc;    // conv2_2+pool
     if ((rc = run_conv(ctx, m->g[2], Bf, N, 16, 16, nullptr, nullptr, A, nullptr, true, false, st))) return rc;   // conv3_1
