@@ -145,8 +145,15 @@ def main():
             ach = d["flops"] / (d["ms"] * 1e-3) / 1e12
             all_ms = sum(v["ms"] for v in convs.values())
             all_fl = sum(v["flops"] for v in convs.values())
+            traffic, tsrc = None, None
+            try:            # HBM bytes per launch of this kernel from the committed rocprofv3 PMC passes (same chunk size)
+                pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))["kernels"].get(name)
+                if pm and pm["images_per_launch"] == args.chunk:
+                    traffic, tsrc = pm["hbm_bytes_corrected"], "profiles/r01_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE, WRITE_SIZE)"
+            except Exception:
+                pass
             out["roofline"] = {"bound": "mfma", "kernel": name, "achieved": ach, "peak": PEAK_F32_MFMA, "unit": "TFLOP/s",
-                               "frac": ach / PEAK_F32_MFMA, "traffic": None,
+                               "frac": ach / PEAK_F32_MFMA, "traffic": traffic, "traffic_source": tsrc,
                                "launches": d["launches"], "avg_launch_ms": d["ms"] / d["launches"],
                                "flops_per_launch": d["flops"] / d["launches"],
                                "all_convs": {"achieved": all_fl / (all_ms * 1e-3) / 1e12,
