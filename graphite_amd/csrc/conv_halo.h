@@ -136,17 +136,20 @@ __global__ __launch_bounds__(WM* WN * 64) void k_conv_halo(HaloParams p) {
 
     // ---- operand streams ----
     //   B: lane reads W[k = 2kk + lh][n0 + j*32 + lp] from global (linear in k across taps), one stage
-    //      (KU k-pairs) ahead, into one of two alternating register sets.
+    //      (KU k-pairs) ahead, into one of two alternating register sets.  The loads are UNCONDITIONAL: the
+    //      stream runs one stage past the end of the weights (make_layer pads the buffer with zero rows).  A
+    //      conditional prefetch makes the compiler's vmcnt bookkeeping assume the shortest path, and the MFMAs of
+    //      a stage then wait for the prefetch issued during that very stage.
     //   A: lane reads tile[pixel + tap][ci = 2kk + lh] from LDS.
-    //      PIPE 0: just in time (the compiler issues each read 1-2 MFMAs ahead of its use);
-    //      PIPE 1: one stage ahead like B, loads interleaved with the current stage's MFMAs
-    //              (sched_group_barrier keeps them from being hoisted into one burst).
+    //      PIPE 0: just in time, B of the next stage loaded as one burst before the stage's MFMAs;
+    //      PIPE 2: A one k-pair ahead, B loads of the next stage interleaved with this stage's MFMAs
+    //              (sched_group_barrier pins: TM A reads, then (TM MFMAs, 1 B load) x TN per k-pair).
     const float* bptr = p.wgt + (size_t)lh * NP + (wn * TN) * 32 + lp;
     float b0r[KU][TN], b1r[KU][TN];
     int nky = 0, nkx = 0, nsub = 0;               // (ky,kx,sub) of the next stage whose A base is needed
     auto next_a_base = [&]() {
         const float* a_tap = smem + nky * RS + nkx * PS + nsub * (2 * KU);
-        if (++nsub == SUBS) { nsub = 0; if (++nkx == KW) { nkx = 0; ++nky; } }
+        if (++nsub == SUBS) { nsub = 0; if (++nkx == KW) { nkx = 0; if (++nky == KH) nky = 0; } }
         return a_tap;
     };
     if (PIPE == 0) {
@@ -176,36 +179,35 @@ __global__ __launch_bounds__(WM* WN * 64) void k_conv_halo(HaloParams p) {
         for (int s = 0; s + 1 < NS; s += 2) {
             load_b(b1r);
             compute(b0r);
-            if (s + 2 < NS) load_b(b0r);
+            load_b(b0r);
             compute(b1r);
         }
         if (NS & 1) compute(b0r);
     } else {
-        float a0r[KU][TM], a1r[KU][TM];
-        // one stage: MFMAs of (bc, ac) while (bn, an) are being filled, k-pair by k-pair
-        auto stage = [&](float (&bc)[KU][TN], float (&ac)[KU][TM], float (&bn)[KU][TN], float (&an)[KU][TM], bool load) {
-            const float* a_tap = load ? next_a_base() : smem;
+        float anext[TM];                          // A values of the next k-pair
+        auto stage = [&](float (&bc)[KU][TN], float (&bn)[KU][TN], const float* a_tap, const float* a_nxt) {
 #pragma unroll
             for (int kk = 0; kk < KU; kk++) {
-                if (load) {
+                float av[TM];
 #pragma unroll
-                    for (int j = 0; j < TN; j++) bn[kk][j] = bptr[(size_t)(2 * kk) * NP + j * 32];
+                for (int i = 0; i < TM; i++) av[i] = anext[i];
 #pragma unroll
-                    for (int i = 0; i < TM; i++) an[kk][i] = a_tap[a_off[i] + 2 * kk];
-                }
+                for (int i = 0; i < TM; i++) anext[i] = kk + 1 < KU ? a_tap[a_off[i] + 2 * (kk + 1)] : a_nxt[a_off[i]];
+#pragma unroll
+                for (int j = 0; j < TN; j++) bn[kk][j] = bptr[(size_t)(2 * kk) * NP + j * 32];
 #pragma unroll
                 for (int i = 0; i < TM; i++)
 #pragma unroll
                     for (int j = 0; j < TN; j++)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(ac[kk][i], bc[kk][j], acc[i][j], 0, 0, 0);
-            }
-            if (load) bptr += (size_t)2 * KU * NP;
-#pragma unroll
-            for (int g = 0; g < KU / 2; g++) {     // per two k-pairs: TM ds_read2, 2*TN global loads, 2*TM*TN MFMAs
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bc[kk][j], acc[i][j], 0, 0, 0);
                 __builtin_amdgcn_sched_group_barrier(0x100, TM, 0);
-                __builtin_amdgcn_sched_group_barrier(0x020, 2 * TN, 0);
-                __builtin_amdgcn_sched_group_barrier(0x008, 2 * TM * TN, 0);
+#pragma unroll
+                for (int j = 0; j < TN; j++) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, TM, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                }
             }
+            bptr += (size_t)2 * KU * NP;
         };
 #pragma unroll
         for (int kk = 0; kk < KU; kk++)
@@ -213,18 +215,16 @@ __global__ __launch_bounds__(WM* WN * 64) void k_conv_halo(HaloParams p) {
             for (int j = 0; j < TN; j++) b0r[kk][j] = bptr[(size_t)(2 * kk) * NP + j * 32];
         bptr += (size_t)2 * KU * NP;
         __syncthreads();                          // the only barrier: tile staged
-        {
-            const float* a_tap = next_a_base();
+        const float* a_cur = next_a_base();
 #pragma unroll
-            for (int kk = 0; kk < KU; kk++)
-#pragma unroll
-                for (int i = 0; i < TM; i++) a0r[kk][i] = a_tap[a_off[i] + 2 * kk];
-        }
+        for (int i = 0; i < TM; i++) anext[i] = a_cur[a_off[i]];
         for (int s = 0; s + 1 < NS; s += 2) {
-            stage(b0r, a0r, b1r, a1r, true);
-            stage(b1r, a1r, b0r, a0r, s + 2 < NS);
+            const float* a1 = next_a_base();
+            stage(b0r, b1r, a_cur, a1);
+            a_cur = next_a_base();                // past the last stage: wraps to tap 0 (value unused)
+            stage(b1r, b0r, a1, a_cur);
         }
-        if (NS & 1) stage(b0r, a0r, b1r, a1r, false);
+        if (NS & 1) stage(b0r, b1r, a_cur, smem);
     }
 
     // ---- epilogue ----

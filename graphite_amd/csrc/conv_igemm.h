@@ -1,6 +1,7 @@
 // conv_igemm.h -- fp32 implicit-GEMM convolution / linear layer on the gfx950 matrix cores.
 //
 //   out[m, co] = epilogue( sum_k A[m, k] * Wp[k, co] ),   m = output pixel, k = (ky, kx, ci)
+//   (or k = (ci/32, ky, kx, ci%32) for the layers the oracle walks in channel chunks, ConvParams::kchunk)
 //
 // * MFMA: v_mfma_f32_32x32x2_f32 (exact f32 in, f32 accumulate).  Each output element is ONE
 //   k-ascending fmaf chain starting from 0 -- no split-K, no multiple accumulators per output --
@@ -34,6 +35,7 @@ struct ConvParams {
     int KH, KW, stride, pad;
     int M;                // B*Ho*Wo
     int relu;
+    int kchunk;           // 0: k = (ky,kx,ci).  BK: k = (ci/BK, ky, kx, ci%BK) -- the order conv_halo_cc.h walks
 };
 
 template <int BK, int WM, int WN, int TM, int TN, bool POOL>
@@ -116,10 +118,17 @@ __global__ __launch_bounds__(WM* WN * 64) void k_conv_igemm(ConvParams p) {
         }
 #pragma unroll
         for (int d = 0; d < DEC; d++) {                 // advance the decode by one chunk
-            a_c[d] += BK;
-            while (a_c[d] >= p.Cin) {
-                a_c[d] -= p.Cin;
-                if (++a_kx[d] == p.KW) { a_kx[d] = 0; ++a_ky[d]; }
+            if (p.kchunk) {                             // next tap of this channel chunk, then the next channel chunk
+                if (++a_kx[d] == p.KW) {
+                    a_kx[d] = 0;
+                    if (++a_ky[d] == p.KH) { a_ky[d] = 0; a_c[d] += BK; }
+                }
+            } else {
+                a_c[d] += BK;
+                while (a_c[d] >= p.Cin) {
+                    a_c[d] -= p.Cin;
+                    if (++a_kx[d] == p.KW) { a_kx[d] = 0; ++a_ky[d]; }
+                }
             }
         }
 #pragma unroll

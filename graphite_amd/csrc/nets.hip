@@ -6,6 +6,7 @@
 #include "common.h"
 #include "conv_igemm.h"
 #include "conv_halo.h"
+#include "conv_halo_cc.h"
 #include <stdlib.h>
 #include <math.h>
 #include <stdarg.h>
@@ -19,6 +20,7 @@ struct Layer {
     float* bias = nullptr;   // [NP]
     int Cin = 0, Cout = 0, NP = 0, KH = 1, KW = 1, stride = 1, pad = 0;
     int CinT = 0;            // true (unpadded) input channels, for the algorithmic flop count
+    int kchunk = 0;          // 32: k = (ci/32, ky, kx, ci%32) (stride-1 3x3 convs with Cin % 32 == 0), else k = (ky,kx,ci)
 };
 struct BnDev { float* scale = nullptr; float* shift = nullptr; };
 struct WrnBlock {
@@ -56,18 +58,25 @@ static int upload(gr_model* m, const std::vector<float>& h, float** d) {
     return GR_OK;
 }
 
-// OIHW -> [k = (ky*KW+kx)*CinP + ci][NP], zero padded in ci (CinP) and co (NP)
+// OIHW -> [k = (ky*KW+kx)*CinP + ci][NP], zero padded in ci (CinP) and co (NP).
+// Stride-1 3x3 convs whose Cin is a multiple of 32 are packed (and accumulated, as in the oracle) in channel
+// chunks of 32: k = ((ci/32)*KH*KW + ky*KW + kx)*32 + ci%32.
 static int make_layer(gr_model* m, Layer* L, const float* w, const float* bias, int Co, int Ci, int KH, int KW, int stride,
                       int pad) {
     int CinP = (Ci + 3) / 4 * 4;
     int bn = n_tile(Co);
     int NP = (Co + bn - 1) / bn * bn;
-    std::vector<float> p((size_t)KH * KW * CinP * NP, 0.f);
+    const int kchunk = (KH == 3 && KW == 3 && stride == 1 && Ci % 32 == 0) ? 32 : 0;
+    std::vector<float> p(((size_t)KH * KW * CinP + 64) * NP, 0.f);   // + 64 zero rows: the halo kernels' B stream reads one stage ahead
     for (int o = 0; o < Co; o++)
         for (int i = 0; i < Ci; i++)
             for (int y = 0; y < KH; y++)
-                for (int x = 0; x < KW; x++)
-                    p[((size_t)(y * KW + x) * CinP + i) * NP + o] = w[(((size_t)o * Ci + i) * KH + y) * KW + x];
+                for (int x = 0; x < KW; x++) {
+                    size_t k = kchunk ? ((size_t)(i / kchunk) * KH * KW + y * KW + x) * kchunk + i % kchunk
+                                      : (size_t)(y * KW + x) * CinP + i;
+                    p[k * NP + o] = w[(((size_t)o * Ci + i) * KH + y) * KW + x];
+                }
+    L->kchunk = kchunk;
     int rc = upload(m, p, &L->w);
     if (rc) return rc;
     if (bias) {
@@ -280,6 +289,9 @@ __global__ void k_argmax_hits(const float* __restrict__ logits, int N, int ncls,
 // ---------------------------------------------------------------------------------------------
 // layer dispatch
 // ---------------------------------------------------------------------------------------------
+static bool use_igemm_convs();
+static int halo_variant(int layer);
+
 static int run_conv(gr_ctx* ctx, const Layer& L, const float* in, int B, int H, int W, const float* res, const BnDev* act,
                     float* out_raw, float* out_act, bool relu, bool pool, hipStream_t st) {
     ConvParams p;
@@ -292,7 +304,7 @@ static int run_conv(gr_ctx* ctx, const Layer& L, const float* in, int B, int H, 
     p.Cout = L.Cout; p.NP = L.NP; p.KH = L.KH; p.KW = L.KW; p.stride = L.stride; p.pad = L.pad;
     long long M = (long long)B * p.Ho * p.Wo;
     if (M > 0x7fffffff - 512) return gr_fail(ctx, GR_EINVAL, "conv: M too large");
-    p.M = (int)M; p.relu = relu ? 1 : 0;
+    p.M = (int)M; p.relu = relu ? 1 : 0; p.kchunk = L.kchunk;
     const int K = L.KH * L.KW * L.Cin;
     const int bn = n_tile(L.Cout);
     int bk = 0;
@@ -308,6 +320,44 @@ static int run_conv(gr_ctx* ctx, const Layer& L, const float* in, int B, int H, 
     const double bytes = 4.0 * ((double)B * H * W * L.CinT + (double)K * L.Cout +
                                 (double)(pool ? M / 4 : M) * L.Cout * ((out_raw ? 1 : 0) + (out_act ? 1 : 0) + (res ? 1 : 0)));
     char pname[64];
+    if (L.kchunk && bk != 32) return gr_fail(ctx, GR_ESTATE, "conv: chunked layer needs BK = 32");
+    if (L.kchunk == 32 && bn == 160 && !pool && !use_igemm_convs() && H == W && (H == 32 || H == 16 || H == 8)) {
+        HaloCcParams q;
+        q.in = in; q.wgt = L.w; q.bias = L.bias; q.res = res; q.scale = p.scale; q.shift = p.shift;
+        q.out_raw = out_raw; q.out_act = out_act;
+        q.B = B; q.H = H; q.W = W; q.Cin = L.Cin; q.Cout = L.Cout; q.NP = L.NP; q.relu = p.relu;
+        const int v = halo_variant(H == 32 ? 0 : H == 16 ? 1 : 2);
+        snprintf(pname, sizeof(pname), "k_conv_halo_cc<%dx%d,v%d>", H, H, v);
+        ProfScope ps_(ctx, pname, st, flops, bytes);
+        //                                   KS  CC  TH  TW NIMG WM WN TM TN KU  RP
+#define HC(...) e = launch_conv_halo_cc<__VA_ARGS__>(q, st)
+        if (H >= 16) {
+            switch (v) {                  // variant 0 = fastest measured (profiles/r01_wrn_tune.md)
+            case 0: HC(3, 32, 16, 16, 1,  4, 1, 2, 5, 4, false, 2); break;
+            case 1: HC(3, 32, 16, 16, 1,  4, 1, 2, 5, 2, false, 2); break;
+            case 2: HC(3, 32, 16, 16, 1,  4, 1, 2, 5, 4, false, 0); break;
+            case 3: HC(3, 32, 16, 16, 1,  4, 1, 2, 5, 4, false, 1); break;
+            case 4: HC(3, 32, 16, 16, 1,  4, 1, 2, 5, 4, false, 4); break;
+            case 5: HC(3, 32, 16, 16, 1,  4, 1, 2, 5, 4, false, 6); break;
+            case 6: HC(3, 32, 16, 16, 1,  8, 1, 1, 5, 4, false, 2); break;
+            default: return gr_fail(ctx, GR_EINVAL, "conv_halo_cc: no variant %d", v);
+            }
+        } else {
+            switch (v) {
+            case 0: HC(3, 32,  8,  8, 4,  4, 1, 2, 5, 4, true , 2); break;
+            case 1: HC(3, 32,  8,  8, 4,  4, 1, 2, 5, 2, true , 2); break;
+            case 2: HC(3, 32,  8,  8, 4,  4, 1, 2, 5, 4, true , 0); break;
+            case 3: HC(3, 32,  8,  8, 4,  4, 1, 2, 5, 4, true , 1); break;
+            case 4: HC(3, 32,  8,  8, 4,  4, 1, 2, 5, 4, true , 4); break;
+            case 5: HC(3, 32,  8,  8, 4,  4, 1, 2, 5, 4, true , 6); break;
+            case 6: HC(3, 32,  8,  8, 4,  8, 1, 1, 5, 4, true , 2); break;
+            default: return gr_fail(ctx, GR_EINVAL, "conv_halo_cc: no variant %d", v);
+            }
+        }
+#undef HC
+        if (e != hipSuccess) return gr_fail(ctx, GR_EHIP, "conv_halo_cc launch (H=%d): %s", H, hipGetErrorString(e));
+        return GR_OK;
+    }
 #define GO(BK_, WM_, WN_, TM_, TN_, POOL_)                                                                        \
     do {                                                                                                          \
         snprintf(pname, sizeof(pname), "k_conv_igemm<%d,%d,%d,%d,%d,%d>", BK_, WM_, WN_, TM_, TN_, (int)POOL_);      \
@@ -375,25 +425,35 @@ static int run_gtsrb_halo(gr_ctx* ctx, const Layer& L, int layer, const float* i
     //                            CIN CPH KH KW  PS  TH  TW NIMG WM WN TM TN  KU   NP  POOL
 #define HL(...) e = launch_conv_halo<__VA_ARGS__>(p, st)
     switch (layer * 8 + v) {            // variant 0 of each layer = the fastest measured (profiles/r01_tune_*.log)
-    case 0 * 8 + 0: HL( 20,  4, 5, 1,   4, 16, 32, 1,  4, 1, 4, 1,  5,  32, false, 0); break;   // conv2_1
-    case 0 * 8 + 1: HL( 20,  4, 5, 1,   4,  8, 32, 1,  4, 1, 2, 1,  5,  32, false, 1); break;
+    case 0 * 8 + 0: HL( 20,  4, 5, 1,   4, 16, 32, 1,  4, 1, 4, 1,  5,  32, false, 2); break;   // conv2_1
+    case 0 * 8 + 1: HL( 20,  4, 5, 1,   4, 16, 32, 1,  4, 1, 4, 1,  5,  32, false, 0); break;
     case 0 * 8 + 2: HL( 20,  4, 5, 1,   4,  8, 32, 1,  4, 1, 2, 1,  5,  32, false, 0); break;
     case 1 * 8 + 0: HL( 32, 32, 5, 5,  33,  8, 32, 1,  4, 1, 2, 1, 16,  32, true , 0); break;   // conv2_2
     case 1 * 8 + 1: HL( 32, 32, 5, 5,  33,  8, 32, 1,  4, 1, 2, 1,  8,  32, true , 0); break;
     case 1 * 8 + 2: HL( 32, 32, 5, 5,  33, 16, 32, 1,  4, 1, 4, 1,  8,  32, true , 0); break;
     case 1 * 8 + 3: HL( 32, 32, 5, 5,  33, 16, 32, 1,  8, 1, 2, 1,  8,  32, true , 0); break;
+    case 1 * 8 + 4: HL( 32, 32, 5, 5,  33,  8, 32, 1,  4, 1, 2, 1, 16,  32, true , 2); break;
+    case 1 * 8 + 5: HL( 32, 32, 5, 5,  33,  8, 32, 1,  4, 1, 2, 1,  8,  32, true , 2); break;
     case 2 * 8 + 0: HL( 32, 32, 5, 5,  33, 16, 16, 1,  2, 2, 4, 1,  8,  64, false, 0); break;   // conv3_1
     case 2 * 8 + 1: HL( 32, 32, 5, 5,  33, 16, 16, 1,  2, 2, 4, 1, 16,  64, false, 0); break;
     case 2 * 8 + 2: HL( 32, 32, 5, 5,  33, 16, 16, 1,  4, 1, 2, 2,  8,  64, false, 0); break;
+    case 2 * 8 + 4: HL( 32, 32, 5, 5,  33, 16, 16, 1,  2, 2, 4, 1,  8,  64, false, 2); break;
+    case 2 * 8 + 5: HL( 32, 32, 5, 5,  33, 16, 16, 1,  2, 2, 4, 1, 16,  64, false, 2); break;
     case 3 * 8 + 0: HL( 64, 64, 5, 5,  65,  8, 16, 1,  2, 2, 2, 1, 16,  64, true , 0); break;   // conv3_2
     case 3 * 8 + 1: HL( 64, 64, 5, 5,  65,  8, 16, 1,  2, 2, 2, 1,  8,  64, true , 0); break;
     case 3 * 8 + 2: HL( 64, 64, 5, 5,  65,  8, 16, 1,  2, 2, 2, 1, 32,  64, true , 0); break;
+    case 3 * 8 + 4: HL( 64, 64, 5, 5,  65,  8, 16, 1,  2, 2, 2, 1, 16,  64, true , 2); break;
+    case 3 * 8 + 5: HL( 64, 64, 5, 5,  65,  8, 16, 1,  2, 2, 2, 1,  8,  64, true , 2); break;
     case 4 * 8 + 0: HL( 64, 64, 5, 5,  65,  8,  8, 2,  1, 4, 4, 1, 16, 128, false, 0); break;   // conv4_1
     case 4 * 8 + 1: HL( 64, 64, 5, 5,  65,  8,  8, 2,  2, 2, 2, 2,  8, 128, false, 0); break;
     case 4 * 8 + 2: HL( 64, 64, 5, 5,  65,  8,  8, 2,  1, 4, 4, 1,  8, 128, false, 0); break;
+    case 4 * 8 + 4: HL( 64, 64, 5, 5,  65,  8,  8, 2,  1, 4, 4, 1, 16, 128, false, 2); break;
+    case 4 * 8 + 5: HL( 64, 64, 5, 5,  65,  8,  8, 2,  1, 4, 4, 1,  8, 128, false, 2); break;
     case 5 * 8 + 0: HL(128,128, 5, 5, 129,  8,  8, 1,  1, 4, 2, 1, 16, 128, true , 0); break;   // conv4_2
     case 5 * 8 + 1: HL(128,128, 5, 5, 129,  8,  8, 1,  1, 4, 2, 1,  8, 128, true , 0); break;
     case 5 * 8 + 2: HL(128,128, 5, 5, 129,  8,  8, 1,  1, 4, 2, 1, 32, 128, true , 0); break;
+    case 5 * 8 + 4: HL(128,128, 5, 5, 129,  8,  8, 1,  1, 4, 2, 1, 16, 128, true , 2); break;
+    case 5 * 8 + 5: HL(128,128, 5, 5, 129,  8,  8, 1,  1, 4, 2, 1,  8, 128, true , 2); break;
     default: return gr_fail(ctx, GR_EINVAL, "conv_halo: no variant %d for layer %d", v, layer);
     }
 #undef HL

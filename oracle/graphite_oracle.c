@@ -324,28 +324,34 @@ static float* repack_oihw(const float* w, int Co, int Ci, int KH, int KW) {
 }
 
 /* out[(oy,ox),co] = chain_k in[(oy*s+ky-pad, ox*s+kx-pad), ci] * wp[k][co]   (zero padding taps skipped:
- * fmaf(0,w,acc)==acc, so skipping is bit-identical) */
+ * fmaf(0,w,acc)==acc, so skipping is bit-identical).
+ * Order of the chain: k = (ky,kx,ci) ascending -- except for stride-1 3x3 convs whose Ci is a multiple of 32
+ * (WideResNet's block convs), which are walked in channel chunks of 32, k = (ci/32, ky, kx, ci%32): the order
+ * of the HIP kernel that keeps a 32-channel slice of the input tile in LDS (csrc/conv_halo_cc.h).  The reference
+ * leaves the order to cuDNN; either order is within 2e-6 relative of its PyTorch forward (tests/golden/nets.npz). */
 static void conv_nhwc(const float* in, int H, int W, int Ci, const float* wp, int KH, int KW, int stride, int pad,
                       float* out, int Ho, int Wo, int Co) {
     float acc[1024];
+    const int cc = (KH == 3 && KW == 3 && stride == 1 && Ci % 32 == 0) ? 32 : Ci;
     for (int oy = 0; oy < Ho; oy++)
         for (int ox = 0; ox < Wo; ox++) {
             for (int o = 0; o < Co; o++) acc[o] = 0.f;
-            for (int ky = 0; ky < KH; ky++) {
-                int iy = oy * stride + ky - pad;
-                if (iy < 0 || iy >= H) continue;
-                for (int kx = 0; kx < KW; kx++) {
-                    int ix = ox * stride + kx - pad;
-                    if (ix < 0 || ix >= W) continue;
-                    const float* a = in + ((size_t)iy * W + ix) * Ci;
-                    const float* wk = wp + (size_t)(ky * KW + kx) * Ci * Co;
-                    for (int i = 0; i < Ci; i++) {
-                        float av = a[i];
-                        const float* wr = wk + (size_t)i * Co;
-                        for (int o = 0; o < Co; o++) acc[o] = fmaf(av, wr[o], acc[o]);
+            for (int c0 = 0; c0 < Ci; c0 += cc)
+                for (int ky = 0; ky < KH; ky++) {
+                    int iy = oy * stride + ky - pad;
+                    if (iy < 0 || iy >= H) continue;
+                    for (int kx = 0; kx < KW; kx++) {
+                        int ix = ox * stride + kx - pad;
+                        if (ix < 0 || ix >= W) continue;
+                        const float* a = in + ((size_t)iy * W + ix) * Ci;
+                        const float* wk = wp + (size_t)(ky * KW + kx) * Ci * Co;
+                        for (int i = c0; i < c0 + cc; i++) {
+                            float av = a[i];
+                            const float* wr = wk + (size_t)i * Co;
+                            for (int o = 0; o < Co; o++) acc[o] = fmaf(av, wr[o], acc[o]);
+                        }
                     }
                 }
-            }
             float* d = out + ((size_t)oy * Wo + ox) * Co;
             for (int o = 0; o < Co; o++) d[o] = acc[o];
         }
