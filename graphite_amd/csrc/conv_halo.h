@@ -142,8 +142,9 @@ __global__ __launch_bounds__(WM* WN * 64) void k_conv_halo(HaloParams p) {
     //      a stage then wait for the prefetch issued during that very stage.
     //   A: lane reads tile[pixel + tap][ci = 2kk + lh] from LDS.
     //      PIPE 0: just in time, B of the next stage loaded as one burst before the stage's MFMAs;
-    //      PIPE 2: A one k-pair ahead, B loads of the next stage interleaved with this stage's MFMAs
-    //              (sched_group_barrier pins: TM A reads, then (TM MFMAs, 1 B load) x TN per k-pair).
+    //      PIPE = AD (+16): A fetched AD k-pairs ahead through a register ring, B loads of the next stage interleaved
+    //              with this stage's MFMAs; without +16 sched_group_barrier pins the order
+    //              (TM A reads, then (TM MFMAs, 1 B load) x TN per k-pair), with +16 the compiler schedules.
     const float* bptr = p.wgt + (size_t)lh * NP + (wn * TN) * 32 + lp;
     float b0r[KU][TN], b1r[KU][TN];
     int nky = 0, nkx = 0, nsub = 0;               // (ky,kx,sub) of the next stage whose A base is needed
@@ -184,15 +185,20 @@ __global__ __launch_bounds__(WM* WN * 64) void k_conv_halo(HaloParams p) {
         }
         if (NS & 1) compute(b0r);
     } else {
-        float anext[TM];                          // A values of the next k-pair
+        // A ring: the values of k-pair kk+AD are fetched while k-pair kk feeds the matrix cores
+        constexpr int AD = (PIPE & 15) ? (PIPE & 15) : 1;
+        constexpr bool PIN = (PIPE & 16) == 0;
+        static_assert(AD >= 1 && KU % AD == 0, "A prefetch distance must divide KU");
+        float aring[AD][TM];
         auto stage = [&](float (&bc)[KU][TN], float (&bn)[KU][TN], const float* a_tap, const float* a_nxt) {
 #pragma unroll
             for (int kk = 0; kk < KU; kk++) {
                 float av[TM];
 #pragma unroll
-                for (int i = 0; i < TM; i++) av[i] = anext[i];
+                for (int i = 0; i < TM; i++) av[i] = aring[kk % AD][i];
 #pragma unroll
-                for (int i = 0; i < TM; i++) anext[i] = kk + 1 < KU ? a_tap[a_off[i] + 2 * (kk + 1)] : a_nxt[a_off[i]];
+                for (int i = 0; i < TM; i++)
+                    aring[kk % AD][i] = kk + AD < KU ? a_tap[a_off[i] + 2 * (kk + AD)] : a_nxt[a_off[i] + 2 * (kk + AD - KU)];
 #pragma unroll
                 for (int j = 0; j < TN; j++) bn[kk][j] = bptr[(size_t)(2 * kk) * NP + j * 32];
 #pragma unroll
@@ -200,11 +206,13 @@ __global__ __launch_bounds__(WM* WN * 64) void k_conv_halo(HaloParams p) {
 #pragma unroll
                     for (int j = 0; j < TN; j++)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bc[kk][j], acc[i][j], 0, 0, 0);
-                __builtin_amdgcn_sched_group_barrier(0x100, TM, 0);
+                if (PIN) {
+                    __builtin_amdgcn_sched_group_barrier(0x100, TM, 0);
 #pragma unroll
-                for (int j = 0; j < TN; j++) {
-                    __builtin_amdgcn_sched_group_barrier(0x008, TM, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                    for (int j = 0; j < TN; j++) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, TM, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                    }
                 }
             }
             bptr += (size_t)2 * KU * NP;
@@ -217,11 +225,13 @@ __global__ __launch_bounds__(WM* WN * 64) void k_conv_halo(HaloParams p) {
         __syncthreads();                          // the only barrier: tile staged
         const float* a_cur = next_a_base();
 #pragma unroll
-        for (int i = 0; i < TM; i++) anext[i] = a_cur[a_off[i]];
+        for (int d = 0; d < AD; d++)
+#pragma unroll
+            for (int i = 0; i < TM; i++) aring[d][i] = a_cur[a_off[i] + 2 * d];
         for (int s = 0; s + 1 < NS; s += 2) {
             const float* a1 = next_a_base();
             stage(b0r, b1r, a_cur, a1);
-            a_cur = next_a_base();                // past the last stage: wraps to tap 0 (value unused)
+            a_cur = next_a_base();                // past the last stage: wraps to tap 0 (values unused)
             stage(b1r, b0r, a1, a_cur);
         }
         if (NS & 1) stage(b0r, b1r, a_cur, smem);

@@ -127,7 +127,7 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void k_conv_halo_cc(HaloCcParams p)
     // the MFMAs of a stage then wait for the prefetch issued during that very stage.
     // Column mapping of the wavefront's TN n-tiles: tile j, lane lp <-> column j*32 + lp.  With VEC (MODEV & 4) tiles
     // are taken in groups of four whose lane `lp` owns the four CONSECUTIVE columns g*128 + 4*lp .. +3 (one 16-byte
-    // load per k-pair, 16-byte stores in the epilogue); measured slower than dword loads (profiles/r01_wrn_tune.md).
+    // load per k-pair, 16-byte stores in the epilogue); measured slower than dword loads (profiles/r01_conv_tune2.md).
     constexpr int TN4 = VEC ? TN / 4 * 4 : 0;
     constexpr int NLD = TN4 / 4 + (TN - TN4);     // B loads per k-pair
     const float* bptr = p.wgt + (size_t)lh * p.NP + n0 + (wn * TN) * 32;

@@ -332,7 +332,7 @@ static int run_conv(gr_ctx* ctx, const Layer& L, const float* in, int B, int H, 
         //                                   KS  CC  TH  TW NIMG WM WN TM TN KU  RP
 #define HC(...) e = launch_conv_halo_cc<__VA_ARGS__>(q, st)
         if (H >= 16) {
-            switch (v) {                  // variant 0 = fastest measured (profiles/r01_wrn_tune.md)
+            switch (v) {                  // variant 0 = fastest measured (profiles/r01_conv_tune2.md)
             case 0: HC(3, 32, 16, 16, 1,  4, 1, 2, 5, 4, false, 2); break;
             case 1: HC(3, 32, 16, 16, 1,  4, 1, 2, 5, 2, false, 2); break;
             case 2: HC(3, 32, 16, 16, 1,  4, 1, 2, 5, 4, false, 0); break;
@@ -425,7 +425,7 @@ static int run_gtsrb_halo(gr_ctx* ctx, const Layer& L, int layer, const float* i
     //                            CIN CPH KH KW  PS  TH  TW NIMG WM WN TM TN  KU   NP  POOL
 #define HL(...) e = launch_conv_halo<__VA_ARGS__>(p, st)
     switch (layer * 8 + v) {            // variant 0 of each layer = the fastest measured (profiles/r01_tune_*.log)
-    case 0 * 8 + 0: HL( 20,  4, 5, 1,   4, 16, 32, 1,  4, 1, 4, 1,  5,  32, false, 2); break;   // conv2_1
+    case 0 * 8 + 0: HL( 20,  4, 5, 1,   4, 16, 32, 1,  4, 1, 4, 1,  5,  32, false, 1); break;   // conv2_1
     case 0 * 8 + 1: HL( 20,  4, 5, 1,   4, 16, 32, 1,  4, 1, 4, 1,  5,  32, false, 0); break;
     case 0 * 8 + 2: HL( 20,  4, 5, 1,   4,  8, 32, 1,  4, 1, 2, 1,  5,  32, false, 0); break;
     case 1 * 8 + 0: HL( 32, 32, 5, 5,  33,  8, 32, 1,  4, 1, 2, 1, 16,  32, true , 0); break;   // conv2_2
@@ -433,27 +433,27 @@ static int run_gtsrb_halo(gr_ctx* ctx, const Layer& L, int layer, const float* i
     case 1 * 8 + 2: HL( 32, 32, 5, 5,  33, 16, 32, 1,  4, 1, 4, 1,  8,  32, true , 0); break;
     case 1 * 8 + 3: HL( 32, 32, 5, 5,  33, 16, 32, 1,  8, 1, 2, 1,  8,  32, true , 0); break;
     case 1 * 8 + 4: HL( 32, 32, 5, 5,  33,  8, 32, 1,  4, 1, 2, 1, 16,  32, true , 2); break;
-    case 1 * 8 + 5: HL( 32, 32, 5, 5,  33,  8, 32, 1,  4, 1, 2, 1,  8,  32, true , 2); break;
+    case 1 * 8 + 6: HL( 32, 32, 5, 5,  33,  8, 32, 1,  4, 1, 2, 1, 16,  32, true , 18); break;
     case 2 * 8 + 0: HL( 32, 32, 5, 5,  33, 16, 16, 1,  2, 2, 4, 1,  8,  64, false, 0); break;   // conv3_1
     case 2 * 8 + 1: HL( 32, 32, 5, 5,  33, 16, 16, 1,  2, 2, 4, 1, 16,  64, false, 0); break;
     case 2 * 8 + 2: HL( 32, 32, 5, 5,  33, 16, 16, 1,  4, 1, 2, 2,  8,  64, false, 0); break;
     case 2 * 8 + 4: HL( 32, 32, 5, 5,  33, 16, 16, 1,  2, 2, 4, 1,  8,  64, false, 2); break;
-    case 2 * 8 + 5: HL( 32, 32, 5, 5,  33, 16, 16, 1,  2, 2, 4, 1, 16,  64, false, 2); break;
+    case 2 * 8 + 6: HL( 32, 32, 5, 5,  33, 16, 16, 1,  2, 2, 4, 1,  8,  64, false, 18); break;
     case 3 * 8 + 0: HL( 64, 64, 5, 5,  65,  8, 16, 1,  2, 2, 2, 1, 16,  64, true , 0); break;   // conv3_2
     case 3 * 8 + 1: HL( 64, 64, 5, 5,  65,  8, 16, 1,  2, 2, 2, 1,  8,  64, true , 0); break;
     case 3 * 8 + 2: HL( 64, 64, 5, 5,  65,  8, 16, 1,  2, 2, 2, 1, 32,  64, true , 0); break;
     case 3 * 8 + 4: HL( 64, 64, 5, 5,  65,  8, 16, 1,  2, 2, 2, 1, 16,  64, true , 2); break;
-    case 3 * 8 + 5: HL( 64, 64, 5, 5,  65,  8, 16, 1,  2, 2, 2, 1,  8,  64, true , 2); break;
+    case 3 * 8 + 6: HL( 64, 64, 5, 5,  65,  8, 16, 1,  2, 2, 2, 1, 16,  64, true , 18); break;
     case 4 * 8 + 0: HL( 64, 64, 5, 5,  65,  8,  8, 2,  1, 4, 4, 1, 16, 128, false, 0); break;   // conv4_1
     case 4 * 8 + 1: HL( 64, 64, 5, 5,  65,  8,  8, 2,  2, 2, 2, 2,  8, 128, false, 0); break;
     case 4 * 8 + 2: HL( 64, 64, 5, 5,  65,  8,  8, 2,  1, 4, 4, 1,  8, 128, false, 0); break;
     case 4 * 8 + 4: HL( 64, 64, 5, 5,  65,  8,  8, 2,  1, 4, 4, 1, 16, 128, false, 2); break;
-    case 4 * 8 + 5: HL( 64, 64, 5, 5,  65,  8,  8, 2,  1, 4, 4, 1,  8, 128, false, 2); break;
+    case 4 * 8 + 6: HL( 64, 64, 5, 5,  65,  8,  8, 2,  1, 4, 4, 1, 16, 128, false, 18); break;
     case 5 * 8 + 0: HL(128,128, 5, 5, 129,  8,  8, 1,  1, 4, 2, 1, 16, 128, true , 0); break;   // conv4_2
     case 5 * 8 + 1: HL(128,128, 5, 5, 129,  8,  8, 1,  1, 4, 2, 1,  8, 128, true , 0); break;
     case 5 * 8 + 2: HL(128,128, 5, 5, 129,  8,  8, 1,  1, 4, 2, 1, 32, 128, true , 0); break;
     case 5 * 8 + 4: HL(128,128, 5, 5, 129,  8,  8, 1,  1, 4, 2, 1, 16, 128, true , 2); break;
-    case 5 * 8 + 5: HL(128,128, 5, 5, 129,  8,  8, 1,  1, 4, 2, 1,  8, 128, true , 2); break;
+    case 5 * 8 + 6: HL(128,128, 5, 5, 129,  8,  8, 1,  1, 4, 2, 1, 16, 128, true , 18); break;
     default: return gr_fail(ctx, GR_EINVAL, "conv_halo: no variant %d for layer %d", v, layer);
     }
 #undef HL
