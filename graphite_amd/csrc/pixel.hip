@@ -235,36 +235,45 @@ __device__ __forceinline__ WarpTaps warp_taps(const double* Mi, int bw0, int x, 
     return t;
 }
 
-__device__ __forceinline__ float gamma_stage(float v, const unsigned char* lut) {
+// gamma stage (transforms.py:69-75): u8 = trunc(v*255); table lookup; /255.0 in double; clip.
+// lutf[u] = clamp01((float)((double)lut[u] / 255.0)) is prepared once per workgroup.
+__device__ __forceinline__ float gamma_stage_f(float v, const float* lutf) {
     float s = v * 255.0f;
-    int u = ((int)s) & 255;
-    float r = (float)((double)lut[u] / 255.0);
-    return clamp01(r);
+    return lutf[((int)s) & 255];
 }
 
 // warped + gamma'd pixel from an RGBX composite
 __device__ __forceinline__ void warp_gamma_rgbx(const float4* __restrict__ att, const double* Mi, int bw0, int x, int y,
-                                                int H, int W, const unsigned char* lut, float* o3) {
+                                                int H, int W, const float* lutf, float* o3) {
     WarpTaps t = warp_taps(Mi, bw0, x, y, H, W);
     float4 a = att[t.o00], b = att[t.o01], c = att[t.o10], d = att[t.o11];
-    o3[0] = gamma_stage(a.x * t.w0 + b.x * t.w1 + c.x * t.w2 + d.x * t.w3, lut);
-    o3[1] = gamma_stage(a.y * t.w0 + b.y * t.w1 + c.y * t.w2 + d.y * t.w3, lut);
-    o3[2] = gamma_stage(a.z * t.w0 + b.z * t.w1 + c.z * t.w2 + d.z * t.w3, lut);
+    o3[0] = gamma_stage_f(a.x * t.w0 + b.x * t.w1 + c.x * t.w2 + d.x * t.w3, lutf);
+    o3[1] = gamma_stage_f(a.y * t.w0 + b.y * t.w1 + c.y * t.w2 + d.y * t.w3, lutf);
+    o3[2] = gamma_stage_f(a.z * t.w0 + b.z * t.w1 + c.z * t.w2 + d.z * t.w3, lutf);
 }
 
 // One workgroup per image n = (candidate, transform).
+// xcd_map: workgroups are dealt round-robin to the 8 XCDs (each with its own L2); with the map on, XCD x gets the
+// x-th contiguous eighth of the launch's images, i.e. (for T ~ chunk/8) the images of ONE candidate, whose composites
+// then stay in that XCD's L2 instead of every L2 streaming every candidate's composites.
 __global__ __launch_bounds__(256) void k_warp_net(const float* __restrict__ att_all, int H, int W, int nslots,
                                                   const XformDev* __restrict__ xf, int T, long long n_begin, int cand0,
-                                                  int normalize, int net, float* __restrict__ out) {
+                                                  int normalize, int net, int count, int xcd_map, float* __restrict__ out) {
     __shared__ double s_Mi[9];
-    __shared__ unsigned char s_lut[256];
+    __shared__ float s_lutf[256];
     __shared__ int s_par[4];
-    const long long n = n_begin + blockIdx.x;
+    int local = blockIdx.x;
+    if (xcd_map) {
+        const int per = (count + 7) >> 3;
+        local = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
+        if (local >= count) return;               // uniform for the workgroup; grid is rounded up to 8 * per
+    }
+    const long long n = n_begin + local;
     const int cand = (int)(n / T) - cand0, t = (int)(n % T);
     const XformDev* x = xf + t;
     const int tid = threadIdx.x;
     if (tid < 9) s_Mi[tid] = x->Mi[tid];
-    if (tid >= 64 && tid < 128) reinterpret_cast<unsigned int*>(s_lut)[tid - 64] = reinterpret_cast<const unsigned int*>(x->lut)[tid - 64];
+    s_lutf[tid] = clamp01((float)((double)x->lut[tid] / 255.0));
     if (tid == 128) { s_par[0] = x->crop_x; s_par[1] = x->crop_y; s_par[2] = x->slot; s_par[3] = x->bw0; }
     __syncthreads();
     const int cw = s_par[0], ch = s_par[1], bw0 = s_par[3];
@@ -272,19 +281,19 @@ __global__ __launch_bounds__(256) void k_warp_net(const float* __restrict__ att_
     const float4* att = reinterpret_cast<const float4*>(att_all) + ((size_t)cand * nslots + s_par[2]) * pl;
     const double scx = 1.0 / ((double)net / (double)cw), scy = 1.0 / ((double)net / (double)ch);
     const bool same = (cw == net && ch == net);
-    float* o = out + (size_t)blockIdx.x * 3 * net * net;
+    float* o = out + (size_t)local * 3 * net * net;
     for (int p = tid; p < net * net; p += 256) {
         int oy = p / net, ox = p % net;
         float r[3];
         if (same) {
-            warp_gamma_rgbx(att, s_Mi, bw0, ox, oy, H, W, s_lut, r);
+            warp_gamma_rgbx(att, s_Mi, bw0, ox, oy, H, W, s_lutf, r);
         } else {
             Tap tx = tap_h(ox, cw, scx), ty = tap_v(oy, ch, scy);
             float g00[3], g01[3], g10[3], g11[3];
-            warp_gamma_rgbx(att, s_Mi, bw0, tx.i0, ty.i0, H, W, s_lut, g00);
-            warp_gamma_rgbx(att, s_Mi, bw0, tx.i1, ty.i0, H, W, s_lut, g01);
-            warp_gamma_rgbx(att, s_Mi, bw0, tx.i0, ty.i1, H, W, s_lut, g10);
-            warp_gamma_rgbx(att, s_Mi, bw0, tx.i1, ty.i1, H, W, s_lut, g11);
+            warp_gamma_rgbx(att, s_Mi, bw0, tx.i0, ty.i0, H, W, s_lutf, g00);
+            warp_gamma_rgbx(att, s_Mi, bw0, tx.i1, ty.i0, H, W, s_lutf, g01);
+            warp_gamma_rgbx(att, s_Mi, bw0, tx.i0, ty.i1, H, W, s_lutf, g10);
+            warp_gamma_rgbx(att, s_Mi, bw0, tx.i1, ty.i1, H, W, s_lutf, g11);
             for (int c = 0; c < 3; c++) {
                 float h0 = g00[c] * tx.w0 + g01[c] * tx.w1;
                 float h1 = g10[c] * tx.w0 + g11[c] * tx.w1;
@@ -383,8 +392,12 @@ int px_warp_net(gr_ctx* ctx, const float* att, int H, int W, const gr_xforms* xf
     if (count <= 0) return GR_OK;
     // algorithmic bytes: 12 B/px written per image + 336 B of transform descriptor read
     ProfScope ps_(ctx, "k_warp_net", st, 0.0, (double)count * (12.0 * net * net + 336.0));
-    hipLaunchKernelGGL(k_warp_net, dim3(count), dim3(256), 0, st, att, H, W, xf->nslots, xf->dev, xf->T,
-                       (long long)n_begin, cand0, normalize, net, out_chw);
+    static int xcd_map = -1;                     // GRAPHITE_WARP_XCD=0 turns the XCD-aware block order off (A/B runs)
+    if (xcd_map < 0) { const char* e = getenv("GRAPHITE_WARP_XCD"); xcd_map = (e && e[0] == '0') ? 0 : 1; }
+    const int use_map = (xcd_map && count >= 64) ? 1 : 0;
+    const int grid = use_map ? 8 * ((count + 7) / 8) : count;
+    hipLaunchKernelGGL(k_warp_net, dim3(grid), dim3(256), 0, st, att, H, W, xf->nslots, xf->dev, xf->T,
+                       (long long)n_begin, cand0, normalize, net, count, use_map, out_chw);
     GR_HIP(ctx, hipGetLastError());
     return GR_OK;
 }
