@@ -238,8 +238,17 @@ def main():
         w = prof.get("k_warp_net")
         if w and w["ms"] > 0:
             gbs = w["bytes"] / (w["ms"] * 1e-3) / 1e9
+            wtr = None
+            try:
+                wtr = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))["kernels"].get("k_warp_net")
+            except Exception:
+                pass
             out["warp_roofline"] = {"bound": "hbm", "kernel": "k_warp_net", "achieved": gbs, "peak": PEAK_HBM, "unit": "GB/s",
-                                    "frac": gbs / PEAK_HBM, "traffic": None, "avg_launch_ms": w["ms"] / w["launches"]}
+                                    "frac": gbs / PEAK_HBM, "traffic": wtr["hbm_bytes_corrected"] if wtr else None,
+                                    "traffic_images_per_launch": wtr["images_per_launch"] if wtr else None,
+                                    "l2_hit_rate": wtr.get("l2_hit_rate") if wtr else None,
+                                    "l2_to_l1_bytes": wtr.get("l2_to_l1_bytes_at_64B_per_req") if wtr else None,
+                                    "avg_launch_ms": w["ms"] / w["launches"]}
         out["kernel_ms"] = {k: round(v["ms"], 3) for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["ms"])}
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

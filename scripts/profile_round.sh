@@ -1,23 +1,40 @@
 #!/bin/bash
-# rocprofv3 evidence for profiles/: kernel-trace stats of bench.py, then HBM-traffic counters
-# (FETCH_SIZE and WRITE_SIZE in separate passes) and SQ busy counters on one GTSRBNet forward.
+# rocprofv3 evidence for profiles/: kernel-trace stats of bench.py, then counter passes (each counter group in a run
+# of its own, as the guide prescribes) on: one GTSRBNet forward (tune_conv.py), one small tr_hits job (prof_tr_hits.py:
+# warp + composite kernels) and one WideResNet-34-10 forward (tune_wrn.py).
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out/prof
-mkdir -p $O && cd /tmp && export TMPDIR=/tmp
-timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/bench -o bench -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline > $O/bench_under_rocprof.json 2> $O/bench.err || exit 1
+rm -rf $O; mkdir -p $O && cd /tmp && export TMPDIR=/tmp
+timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/bench -o bench -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extras > $O/bench_under_rocprof.json 2> $O/bench.err || exit 1
 rm -f $O/bench/*kernel_trace.csv
-timeout -s KILL 120 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/fetch -o fetch -- python3 $R/scripts/tune_conv.py 8192 > $O/fetch.log 2>&1 || exit 2
-timeout -s KILL 120 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/write -o write -- python3 $R/scripts/tune_conv.py 8192 > $O/write.log 2>&1 || exit 3
-timeout -s KILL 120 rocprofv3 --pmc SQ_BUSY_CYCLES SQ_WAVES SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_VALU_MFMA_BUSY_CYCLES --output-format csv -d $O/sq -o sq -- python3 $R/scripts/tune_conv.py 8192 > $O/sq.log 2>&1 || echo "sq pass failed (non-fatal)"
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/wrn -o wrn -- python3 $R/scripts/tune_wrn.py 1024 > $O/wrn_under_rocprof.log 2> $O/wrn.err || exit 1
+rm -f $O/wrn/*kernel_trace.csv
+pass() {   # name, counters, program...
+  local name=$1 ctr=$2; shift 2
+  timeout -s KILL 150 rocprofv3 --pmc $ctr --output-format csv -d $O/$name -o $name -- python3 "$@" > $O/$name.log 2>&1 || { echo "pass $name failed"; return 1; }
+}
+pass fetch_gtsrb "FETCH_SIZE" $R/scripts/tune_conv.py 8192 || exit 2
+pass write_gtsrb "WRITE_SIZE" $R/scripts/tune_conv.py 8192 || exit 3
+pass sq_gtsrb "SQ_BUSY_CYCLES SQ_WAVES SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_VALU_MFMA_BUSY_CYCLES" $R/scripts/tune_conv.py 8192 || echo non-fatal
+pass fetch_trhits "FETCH_SIZE" $R/scripts/prof_tr_hits.py || exit 4
+pass write_trhits "WRITE_SIZE" $R/scripts/prof_tr_hits.py || exit 5
+pass tcc_trhits "TCC_HIT_sum TCC_MISS_sum" $R/scripts/prof_tr_hits.py || echo non-fatal
+pass tcp_trhits "TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum" $R/scripts/prof_tr_hits.py || echo non-fatal
+pass fetch_wrn "FETCH_SIZE" $R/scripts/tune_wrn.py 1024 || exit 6
+pass write_wrn "WRITE_SIZE" $R/scripts/tune_wrn.py 1024 || exit 7
+pass sq_wrn "SQ_BUSY_CYCLES SQ_WAVES SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_VALU_MFMA_BUSY_CYCLES" $R/scripts/tune_wrn.py 1024 || echo non-fatal
 python3 - <<'PY'
 import csv, glob, os, collections
 O = os.environ.get("GRAFT_REPO_ROOT", os.getcwd()) + "/gpurun_out/prof"
-for name in ("fetch", "write", "sq"):
-    files = glob.glob(f"{O}/{name}/**/*counter_collection.csv", recursive=True)
+for d in sorted(glob.glob(f"{O}/*/")):
+    name = os.path.basename(d.rstrip("/"))
+    files = glob.glob(f"{d}/**/*counter_collection.csv", recursive=True)
+    if not files:
+        continue
     agg = collections.defaultdict(lambda: collections.defaultdict(list))
     for f in files:
         for r in csv.DictReader(open(f)):
-            agg[r["Kernel_Name"][:60]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+            agg[r["Kernel_Name"][:90]][r["Counter_Name"]].append(float(r["Counter_Value"]))
         os.remove(f)
     with open(f"{O}/{name}_summary.csv", "w") as out:
         out.write("kernel,counter,dispatches,mean,sum\n")
@@ -25,4 +42,4 @@ for name in ("fetch", "write", "sq"):
             for c, v in cs.items():
                 out.write(f"\"{k}\",{c},{len(v)},{sum(v)/len(v):.6g},{sum(v):.6g}\n")
 PY
-find $O -type f | head -40
+find $O -type f | head -60
