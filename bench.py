@@ -89,6 +89,24 @@ def extras(_hip, engine, models, synth):
             "conv_frac_of_f32_mfma_peak": cfl / (cms * 1e-3) / 1e12 / PEAK_F32_MFMA if cms else None,
             "hits_checksum": int(h.sum().item())}
     del wrn
+    # ---- config 5: PatchGuard parameter table (pg_transforms.py:67-94, baseline=True); the BagNet robust classifier is
+    # un-vendored third-party code with no weights here, so only the warp stage is timed
+    pg = cifar_case(num_xforms=100, patchguard=True, baseline=True)
+    C5 = 512
+    masks = np.concatenate([pg["hull"][None], synth.synth_patch_masks("bench-pg", C5 - 1, pg["hull"])])
+    thetas = ((pg["tar_s"] - pg["vic_s"])[None] * masks).astype(np.float32)
+    i5, m5, t5 = _hip.to_dev(pg["vic"]), _hip.to_dev(masks), _hip.to_dev(thetas)
+    _hip.warp_batch_dev(i5, m5, t5, pg["tab"], 1.0, True)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(5):
+        o5 = _hip.warp_batch_dev(i5, m5, t5, pg["tab"], 1.0, True)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / 5
+    res["config5_patchguard_table_warp_only"] = {
+        "images_per_s": C5 * 100 / dt, "ms_per_launch": 1e3 * dt, "candidates": C5, "transforms": 100,
+        "output_gb_per_s": C5 * 100 * 12288 / dt / 1e9, "checksum": float(o5.double().sum().item())}
+    del o5
     # ---- config 2
     a = parsearguments.getarguments(["-v", "14", "-t", "1", "--tr_lo", "0.65", "--tr_hi", "0.85", "-m", "100", "-b", "100",
                                      "--coarse_mode", "binary", "--seed", "42"])
