@@ -205,7 +205,9 @@ extern "C" void gr_xforms_destroy(gr_xforms* x) {
 // ---------------------------------------------------------------------------------------------
 // pixel operators
 // ---------------------------------------------------------------------------------------------
-#define NEED_CTX() do { if (!ctx) return GR_EINVAL; } while (0)
+// every entry point makes the context's device current for the calling thread (kernel launches and the workspace
+// allocation must not land on whatever device the caller last selected)
+#define NEED_CTX() do { if (!ctx) return GR_EINVAL; GR_HIP(ctx, hipSetDevice(ctx->device)); } while (0)
 
 extern "C" int gr_resize_linear(gr_ctx* ctx, const float* src, int C, int sh, int sw, float* dst, int dh, int dw, void* stream) {
     NEED_CTX();

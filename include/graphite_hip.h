@@ -18,6 +18,7 @@
  *    gr_xforms and gr_model objects and a growable device workspace inside gr_ctx.
  *  - `stream` is a hipStream_t passed as void* (NULL = the null stream).  Calls enqueue work
  *    on it and return without synchronising unless stated; one host thread per gr_ctx.
+ *    Every call makes the context's device the calling thread's current HIP device.
  *  - Images are planar CHW float32.  Candidate c = (mask[c], theta[c]); image n = c*T + t.
  */
 #ifndef GRAPHITE_HIP_H

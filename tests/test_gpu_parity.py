@@ -126,6 +126,38 @@ def test_edge_cases(oracle):
         _hip.XformTable(bad)
 
 
+def test_c_abi_error_codes(gtsrb_model):
+    """Errors come back as negative codes with a message; nothing is launched and nothing throws across the ABI."""
+    lib, ctx = _hip.load_library(), _hip.ctx()
+    case = gtsrb_case()
+    masks, thetas = gtsrb_candidates(case, 2)
+    i, m, t = _hip.to_dev(case["vic"]), _hip.to_dev(masks), _hip.to_dev(thetas)
+    xf = _hip.xform_table(case["tab"][:10])
+    hits = torch.zeros(2, dtype=torch.int32, device="cuda")
+    h = gtsrb_model.hip_model._h
+    P = _hip._p
+
+    def call(model=h, img=P(i), C=2, begin=0, count=20, hits_p=P(hits), c=ctx):
+        return lib.gr_tr_hits(c, model, img, 244, 244, P(m), P(t), C, 32, 32, xf._h, 1.0, 1, 1, begin, count, hits_p, None, None,
+                              None)
+
+    assert call() == 0
+    assert call(model=None) == -1 and b"bad arguments" in lib.gr_last_error(ctx)            # GR_EINVAL
+    assert call(img=None) == -1
+    assert call(hits_p=None) == -1
+    assert call(begin=5, count=16) == -1 and b"slice out of range" in lib.gr_last_error(ctx)
+    assert call(begin=-1) == -1
+    assert call(C=-3) == -1
+    assert call(c=None) == -1                                                                 # no context: code only
+    assert call(begin=20, count=0) == 0                                                       # empty slice is fine
+    assert lib.gr_ctx_set_chunk(ctx, 7) == -1 and b"chunk" in lib.gr_last_error(ctx)
+    assert lib.gr_model_forward(ctx, h, None, 4, None, None) == -1
+    torch.cuda.synchronize()
+    # the context still works after the failures
+    got, _, _ = _hip.tr_hits_dev(gtsrb_model.hip_model, i, m, t, case["tab"][:10], 1.0, True, 1)
+    assert got.shape == (2,) and int(got.max()) <= 10
+
+
 def test_reference_signatures(oracle):
     """get_transformed_images / apply_transformation / convert2Network return what the reference returns."""
     case = gtsrb_case()
