@@ -60,7 +60,16 @@ __global__ __launch_bounds__(WM* WN * 64) void k_conv_halo(HaloParams p) {
     const int wm = wave / WN, wn = wave % WN;
     const int lp = lane & 31, lh = lane >> 5;
     const int tiles_x = p.W / TW, tiles_y = p.H / TH;
-    int bid = blockIdx.x;
+    // Workgroups are dealt round-robin to the 8 XCDs (one L2 each).  Decode blockIdx so that all tiles of one image
+    // group run on the SAME XCD, back to back: the halo rows two neighbouring tiles share are then read from HBM once.
+    int bid;
+    {
+        const int tpi = tiles_x * tiles_y, groups = (p.B + NIMG - 1) / NIMG;
+        const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+        const int g = (j / tpi) * 8 + xcd;
+        if (g >= groups) return;                  // grid is rounded up to a multiple of 8 groups; whole workgroup leaves
+        bid = g * tpi + j % tpi;
+    }
     const int tx = bid % tiles_x; bid /= tiles_x;
     const int ty = bid % tiles_y; bid /= tiles_y;
     const int b0 = bid * NIMG;
@@ -299,6 +308,7 @@ static inline hipError_t launch_conv_halo(const HaloParams& p, hipStream_t st) {
         attr_set = true;
     }
     int groups = (p.B + NIMG - 1) / NIMG;
+    groups = (groups + 7) / 8 * 8;                // see the blockIdx decode in the kernel
     dim3 grid((unsigned)(groups * (p.H / TH) * (p.W / TW)));
     hipLaunchKernelGGL(kern, grid, dim3(WM * WN * 64), smem, st, p);
     return hipGetLastError();

@@ -63,12 +63,24 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void k_conv_halo_cc(HaloCcParams p)
     const int wm = wave / WN, wn = wave % WN;
     const int lp = lane & 31, lh = lane >> 5;
     const int tiles_x = p.W / TW, tiles_y = p.H / TH;
-    int bid = blockIdx.x;
+    // 1-D grid, decoded XCD-aware (workgroups are dealt round-robin to the 8 XCDs, one L2 each): the N tiles of one
+    // spatial tile, then the spatial tiles of one image group, run back to back on the SAME XCD, so the input slice
+    // they share (whole tile / halo rows) comes from that XCD's L2.
+    int bid, ntile;
+    {
+        const int tpi = tiles_x * tiles_y, groups = (p.B + NIMG - 1) / NIMG, nts = p.NP / (WN * TN * 32);
+        const int xcd = blockIdx.x & 7;
+        int j = blockIdx.x >> 3;
+        ntile = j % nts; j /= nts;
+        const int g = (j / tpi) * 8 + xcd;
+        if (g >= groups) return;                  // grid is rounded up to a multiple of 8 groups; whole workgroup leaves
+        bid = g * tpi + j % tpi;
+    }
     const int tx = bid % tiles_x; bid /= tiles_x;
     const int ty = bid % tiles_y; bid /= tiles_y;
     const int b0 = bid * NIMG;
     const int y0 = ty * TH, x0 = tx * TW;
-    const int n0 = blockIdx.y * (WN * TN * 32);
+    const int n0 = ntile * (WN * TN * 32);
 
     // ---- stage channels [c0, c0+CC) of the haloed tile (zero outside the image / batch) ----
     auto stage_tile = [&](int c0) {
@@ -285,8 +297,11 @@ static inline hipError_t launch_conv_halo_cc(const HaloCcParams& p, hipStream_t 
     }
     if (p.H % TH || p.W % TW || p.Cin % CC || p.NP % (WN * TN * 32) || p.Cout % 4 || (p.out_act && !(p.scale && p.shift)))
         return hipErrorInvalidValue;
-    int groups = (p.B + NIMG - 1) / NIMG;
-    dim3 grid((unsigned)(groups * (p.H / TH) * (p.W / TW)), (unsigned)(p.NP / (WN * TN * 32)));
+    long long groups = (p.B + NIMG - 1) / NIMG;
+    groups = (groups + 7) / 8 * 8;                // see the blockIdx decode in the kernel
+    const long long nblk = groups * (p.H / TH) * (p.W / TW) * (p.NP / (WN * TN * 32));
+    if (nblk > 0x7fffffffLL) return hipErrorInvalidValue;
+    dim3 grid((unsigned)nblk);
     hipLaunchKernelGGL(kern, grid, dim3(WM * WN * 64), smem, st, p);
     return hipGetLastError();
 }
