@@ -107,25 +107,19 @@ def extras(_hip, engine, models, synth):
         "images_per_s": C5 * 100 / dt, "ms_per_launch": 1e3 * dt, "candidates": C5, "transforms": 100,
         "output_gb_per_s": C5 * 100 * 12288 / dt / 1e9, "checksum": float(o5.double().sum().item())}
     del o5
-    # ---- config 2
-    a = parsearguments.getarguments(["-v", "14", "-t", "1", "--tr_lo", "0.65", "--tr_hi", "0.85", "-m", "100", "-b", "100",
+    # ---- config 2: stop sign -> pedestrians, as BASELINE config 2.  The authors' checkpoint is not available; the classifier
+    # is the seeded GTSRBNet with the fitted 3-sign read-out (synth.gtsrb_state_dict(readout="toy3"),
+    # tests/golden/make_toy_readout.py), so the searches take real accept / reject decisions.
+    a = parsearguments.getarguments(["-v", "14", "-t", "27", "--tr_lo", "0.65", "--tr_hi", "0.85", "-m", "100", "-b", "100",
                                      "--coarse_mode", "binary", "--seed", "42"])
     model = models.GTSRBNet()
-    model.load_state_dict(synth.gtsrb_state_dict())
-    # the synthetic classifier knows no "speed limit 30": the label it most often gives the fully pasted target under
-    # the transforms plays the target class, so that the searches take real accept/reject decisions
-    from cases import gtsrb_case
-    g = gtsrb_case(num_xforms=100)
-    m0 = g["hull"][None]
-    th0 = ((g["tar_s"] - g["vic_s"])[None] * m0).astype(np.float32)
-    _, preds = engine.tr_hits(model, g["vic"], m0, th0, g["tab"], 1, return_preds=True)
-    lbl_t = int(torch.mode(preds.flatten().cpu()).values.item())
+    model.load_state_dict(synth.gtsrb_state_dict(readout="toy3"))
     np.random.seed(42); torch.manual_seed(42); random.seed(42)
     t0 = time.perf_counter()
     with contextlib.redirect_stdout(io.StringIO()):
         r = gmain.attack_network(
-            model, os.path.join(INP, "GTSRB/images/14.png"), os.path.join(INP, "GTSRB/images/1.png"),
-            os.path.join(INP, "GTSRB/Hulls/14.png"), 14, lbl_t, os.path.join(INP, "GTSRB/Points/14.csv"), "score.py", "Target",
+            model, os.path.join(INP, "GTSRB/images/14.png"), os.path.join(INP, "GTSRB/images/27.png"),
+            os.path.join(INP, "GTSRB/Hulls/14.png"), 14, 27, os.path.join(INP, "GTSRB/Points/14.csv"), "score.py", "Target",
             a.coarse_error, a.reduce_error, 1, 100, 100, model_type='GTSRB', args=a, write_outputs=False)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
@@ -133,9 +127,8 @@ def extras(_hip, engine, models, synth):
         "wall_clock_s": dt, "queries": int(r["queries"]), "mask_queries": int(r["mask_queries"]),
         "boost_queries": int(r["boost_queries"]), "queries_per_s": r["queries"] / dt,
         "final_mask_pixels": int(r["pixels"]), "transform_robustness": float(r["transform_robustness"]),
-        "target_label": lbl_t,
-        "note": "stop sign 14 -> target image 1.png, -m 100 -b 100, binary coarse reduction, seed 42, seeded synthetic GTSRBNet weights "
-                "(reference: ~10 min on an RTX 3080 with the authors' checkpoint, README.md:26)"}
+        "note": "stop sign 14 -> pedestrians 27, -m 100 -b 100, binary coarse reduction, seed 42; seeded GTSRBNet with a fitted "
+                "3-sign read-out (the authors' checkpoint is unavailable; reference: ~10 min on an RTX 3080, README.md:26)"}
     return res
 
 

@@ -70,12 +70,16 @@ def _calibrated_bias(tag):
     return np.load(path, allow_pickle=False).astype(np.float32)
 
 
-def gtsrb_state_dict(tag: str = "gtsrb-v1", calibrated: bool = True):
+def gtsrb_state_dict(tag: str = "gtsrb-v1", calibrated: bool = True, readout: str = None):
     """dict[str, np.ndarray float32] with the reference's state_dict keys.
 
     He-uniform weights (bound sqrt(6/fan_in)) keep the activations O(1) through
     the net so the 43 logits are well separated for most inputs; biases are
     small uniform values.
+
+    readout="toy3": fc7 is replaced by the linear read-out fitted by tests/golden/make_toy_readout.py on
+    transformed views of the three sign images the reference ships (classes 14, 1, 27): a classifier whose
+    decisions mean something, for whole-attack runs.
     """
     sd = {}
     for name, shape in GTSRB_SHAPES:
@@ -83,7 +87,13 @@ def gtsrb_state_dict(tag: str = "gtsrb-v1", calibrated: bool = True):
         bound = float(np.sqrt(6.0 / fan_in))
         sd[name + ".weight"] = hash_uniform(f"{tag}/{name}.weight", shape, -bound, bound)
         sd[name + ".bias"] = hash_uniform(f"{tag}/{name}.bias", (shape[0],), -0.05, 0.05)
-    if calibrated:
+    if readout is not None:
+        import os
+        f = os.path.join(os.path.dirname(os.path.abspath(__file__)), "data", f"{tag}_{readout}_fc7.npz")
+        z = np.load(f)
+        sd["fc7_1.weight"] = np.ascontiguousarray(z["weight"], dtype=np.float32)
+        sd["fc7_1.bias"] = np.ascontiguousarray(z["bias"], dtype=np.float32)
+    elif calibrated:
         sd["fc7_1.bias"] = _calibrated_bias(tag)
     return sd
 

@@ -16,9 +16,8 @@ from oracle_evaluator import OracleEvaluator
 pytestmark = pytest.mark.gpu
 
 
-def _run(evaluator, T, target):
-    args = parsearguments.getarguments(["-v", "14", "-t", str(target), "--tr_lo", "0.3", "--tr_hi", "0.5"])
-    sd = synth.gtsrb_state_dict()
+def _run(evaluator, T, target, sd):
+    args = parsearguments.getarguments(["-v", "14", "-t", str(target), "--tr_lo", "0.65", "--tr_hi", "0.85"])
     model = models.GTSRBNet()
     model.load_state_dict(sd)
     np.random.seed(42); torch.manual_seed(42); random.seed(42)
@@ -30,12 +29,14 @@ def _run(evaluator, T, target):
 
 
 def test_attack_trajectory_matches_oracle():
-    T = 12
-    # the synthetic classifier's most frequent label on this scene plays the role of the target class
-    target = 1
-    sd = synth.gtsrb_state_dict()
-    gpu = _run(None, T, target)
-    cpu = _run(OracleEvaluator.factory(sd), T, target)
+    # stop sign -> pedestrians with the fitted 3-sign read-out: the coarse / fine reductions and the boosting take
+    # real accept / reject decisions, every one of which hinges on a hit count
+    T = 20
+    target = 27
+    sd = synth.gtsrb_state_dict(readout="toy3")
+    gpu = _run(None, T, target, sd)
+    cpu = _run(OracleEvaluator.factory(sd), T, target, sd)
+    assert 0 < gpu["pixels"] < 702 and gpu["queries"] > 1000          # the mask was really reduced
     assert gpu["queries"] == cpu["queries"] and gpu["pixels"] == cpu["pixels"]
     assert gpu["transform_robustness"] == cpu["transform_robustness"]
     assert torch.equal(gpu["mask"], cpu["mask"])
