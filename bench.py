@@ -107,6 +107,42 @@ def extras(_hip, engine, models, synth):
         "images_per_s": C5 * 100 / dt, "ms_per_launch": 1e3 * dt, "candidates": C5, "transforms": 100,
         "output_gb_per_s": C5 * 100 * 12288 / dt / 1e9, "checksum": float(o5.double().sum().item())}
     del o5
+    # ---- whitebox EOT gradient: forward + backward of transform_wb for 100 transforms of the stop sign,
+    # the inner body of whitebox_attack.py:149-162 without the classifier; checked against the torch restatement
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import wb_reference as WR
+    from cases import gtsrb_case as _gc, PT14
+    from graphite_amd import transforms as GT
+    g100 = _gc(num_xforms=100)
+    gen = torch.Generator().manual_seed(0)
+    orig = torch.from_numpy(0.04 + 0.92 * g100["vic"])
+    attw = torch.clamp(orig + 0.25 * torch.randn(orig.shape, generator=gen), 0.03, None)
+    maskw = torch.zeros(3, 244, 244)
+    maskw[:, 40:200, 30:215] = 1.0
+    wtab = GT.build_wb_table(g100["xf"], 244, 244, PT14)
+    od, ad, md = _hip.to_dev(orig), _hip.to_dev(attw), _hip.to_dev(maskw)
+    gout = torch.randn(100, 3, 32, 32, generator=gen).to(od.device)
+    for _ in range(3):
+        _hip.wb_forward(od, ad, md, wtab); gg = _hip.wb_backward(od, ad, md, wtab, gout)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(20):
+        _hip.wb_forward(od, ad, md, wtab); gg = _hip.wb_backward(od, ad, md, wtab, gout)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / 20
+    t0 = time.perf_counter()
+    a_ref = attw.clone().requires_grad_(True)
+    outs = []
+    for t in range(100):
+        xf = g100["tab"][t]
+        outs.append(WR.transform_wb(orig[None], a_ref[None], maskw, xf["M"].reshape(3, 3), int(xf["crop_x"]), int(xf["crop_y"]),
+                                    float(g100["xf"][t][2]), int(g100["xf"][t][3])))
+    (torch.cat(outs) * gout.cpu()).sum().backward()
+    cdt = time.perf_counter() - t0
+    res["whitebox_eot_gradient"] = {
+        "transforms": 100, "ms_fwd_plus_bwd": 1e3 * dt, "eot_gradients_per_s": 1.0 / dt,
+        "cpu_torch_reference_ms": 1e3 * cdt, "cpu_threads": torch.get_num_threads(),
+        "grad_max_err_over_max": float((gg.cpu() - a_ref.grad).abs().max() / a_ref.grad.abs().max())}
     # ---- config 2: stop sign -> pedestrians, as BASELINE config 2.  The authors' checkpoint is not available; the classifier
     # is the seeded GTSRBNet with the fitted 3-sign read-out (synth.gtsrb_state_dict(readout="toy3"),
     # tests/golden/make_toy_readout.py), so the searches take real accept / reject decisions.

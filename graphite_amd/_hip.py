@@ -47,7 +47,12 @@ SIGNATURES = {
     "gr_model_forward": (_i, [_vp, _vp, _vp, _i, _vp, _vp]),
     "gr_model_predict": (_i, [_vp, _vp, _vp, _i, _vp, _vp]),
     "gr_tr_hits": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp, _i, _i, _i, _vp, _f, _i, _i, _i64, _i64, _vp, _vp, _vp, _vp]),
+    "gr_wb_forward": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp, _i, _i, _vp, _vp]),
+    "gr_wb_backward": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp, _i, _i, _vp, _vp, _vp]),
 }
+
+WB_XFORM_DTYPE = np.dtype([("A", np.float32, (9,)), ("crop_x", np.int32), ("crop_y", np.int32),
+                           ("gamma", np.float32), ("blur", np.int32)], align=True)
 
 _lib = None
 _lock = threading.Lock()
@@ -314,3 +319,30 @@ def tr_hits_dev(model, img, masks, thetas, tab, lbd, normalize, target, img_begi
                                                  int(normalize), int(target), int(img_begin), int(img_count), _p(hits),
                                                  _p(preds), _p(logits), _stream()), "gr_tr_hits")
     return hits, preds, logits
+
+
+# ------------------------------------------------------------------------------------------------
+# differentiable ("whitebox") transform
+# ------------------------------------------------------------------------------------------------
+def wb_forward(orig, att, mask, tab, net=32):
+    """[T,3,net,net] CUDA tensor: transform_wb of (orig, att, mask) under every descriptor of `tab` (WB_XFORM_DTYPE)."""
+    o, a, m = to_dev(orig), to_dev(att), to_dev(mask)
+    tab = np.ascontiguousarray(tab, dtype=WB_XFORM_DTYPE)
+    _, H, W = o.shape
+    assert a.shape == o.shape == m.shape
+    out = torch.empty((len(tab), 3, net, net), device=o.device, dtype=torch.float32)
+    _check(ctx(), load_library().gr_wb_forward(ctx(), _p(o), _p(a), _p(m), H, W, tab.ctypes.data_as(_vp), len(tab), net,
+                                               _p(out), _stream()), "gr_wb_forward")
+    return out
+
+
+def wb_backward(orig, att, mask, tab, grad_out, net=32):
+    """d loss / d att [3,H,W] (summed over the T transforms) given d loss / d out [T,3,net,net]."""
+    o, a, m, g = to_dev(orig), to_dev(att), to_dev(mask), to_dev(grad_out)
+    tab = np.ascontiguousarray(tab, dtype=WB_XFORM_DTYPE)
+    _, H, W = o.shape
+    assert g.shape == (len(tab), 3, net, net)
+    ga = torch.empty_like(a)
+    _check(ctx(), load_library().gr_wb_backward(ctx(), _p(o), _p(a), _p(m), H, W, tab.ctypes.data_as(_vp), len(tab), net,
+                                                _p(g), _p(ga), _stream()), "gr_wb_backward")
+    return ga

@@ -112,11 +112,14 @@ def get_perspective_transform(img, angle, w, h, f, d, crop_percent, crop_off_x, 
                               pt_file='inputs/GTSRB/Points/14.csv', whitebox=False):
     """Warp an HWC float32 numpy image as the reference does (:8-51); returns HWC [crop_y,crop_x,3].
 
-    The pixel work runs in the HIP library (gr_warp_perspective); `whitebox=True`
-    (the kornia/autograd twin, :49) is out of scope for this path.
+    The pixel work runs in the HIP library (gr_warp_perspective).  `whitebox=True` (the kornia branch, :49) is
+    not offered as a stand-alone warp: the differentiable path is fused end to end in
+    graphite_amd.transforms.transform_wb / transform_wb_batch (gr_wb_forward / gr_wb_backward), which never
+    materialise the warped crop.
     """
     if whitebox:
-        raise NotImplementedError("whitebox (differentiable) warp is outside the transform-robustness scoring path")
+        raise NotImplementedError("use graphite_amd.transforms.transform_wb: the differentiable warp is fused with "
+                                  "gamma and resize and has no stand-alone form")
     from . import _hip
     M, crop_x, crop_y = perspective_matrix(angle, w, h, f, d, crop_percent, crop_off_x, crop_off_y, pt_file)
     return _hip.warp_perspective_hwc(np.ascontiguousarray(img, dtype=np.float32), M, crop_x, crop_y)

@@ -177,3 +177,90 @@ def get_transformed_images(image, mask, transforms, lbd, theta, pt_file='inputs/
                           net_size)
     t = torch.from_numpy(out[0])
     return [t[i] for i in range(t.shape[0])]
+
+
+# ------------------------------------------------------------------------------------------------
+# differentiable ("whitebox") twin: transform_wb / convert2NetworkWB (reference :176-228)
+# ------------------------------------------------------------------------------------------------
+def _normal_transform_pixel(h, w):
+    """kornia.geometry.conversions.normal_transform_pixel (0.5.10): pixel -> [-1, 1] coordinates, float32."""
+    tr = torch.tensor([[1.0, 0.0, -1.0], [0.0, 1.0, -1.0], [0.0, 0.0, 1.0]], dtype=torch.float32)
+    tr[0, 0] = tr[0, 0] * 2.0 / (w - 1 if w > 1 else 1e-14)
+    tr[1, 1] = tr[1, 1] * 2.0 / (h - 1 if h > 1 else 1e-14)
+    return tr
+
+
+def build_wb_table(transforms, w, h, pt_file):
+    """Per-transform descriptors of the whitebox kernels (gr_wb_xform): what transform_wb (:177-204) and
+    kornia.warp_perspective's normalize_homography compute per call -- the float32 matrix that takes normalised
+    dst coordinates to normalised src coordinates, the warp's dsize, gamma and the blur kernel size."""
+    from ._hip import WB_XFORM_DTYPE
+    tab = np.zeros(len(transforms), dtype=WB_XFORM_DTYPE)
+    n_src_inv = torch.inverse(_normal_transform_pixel(h, w))
+    for i, tr in enumerate(transforms):
+        angle, dist, gamma, blur, crop_percent, crop_off_x, crop_off_y, obj_width, focal, _ = tr
+        d = dist2pixels(dist, h, obj_width)            # the reference passes att.size()[2] = H here (:200-201)
+        f = dist2pixels(focal, h, obj_width)
+        M, cx, cy = perspective_matrix(angle, w, h, f, d, crop_percent, crop_off_x, crop_off_y, pt_file)
+        M32 = torch.from_numpy(np.asarray(M, np.float64)).float()
+        dst_norm_trans_src_norm = _normal_transform_pixel(cy, cx) @ (M32 @ n_src_inv)
+        tab[i]["A"] = torch.inverse(dst_norm_trans_src_norm).numpy().reshape(9)
+        tab[i]["crop_x"], tab[i]["crop_y"], tab[i]["gamma"], tab[i]["blur"] = cx, cy, gamma, int(blur)
+    return tab
+
+
+class _TransformWB(torch.autograd.Function):
+    """out[T,3,net,net] = transform_wb(orig, att, mask, transform_t); differentiable w.r.t. att (HIP backward kernels)."""
+
+    @staticmethod
+    def forward(ctx, att, orig, mask, tab, net):
+        from . import _hip
+        ctx.save_for_backward(att, orig, mask)
+        ctx.tab, ctx.net = tab, net
+        return _hip.wb_forward(orig, att, mask, tab, net)
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        from . import _hip
+        att, orig, mask = ctx.saved_tensors
+        g = _hip.wb_backward(orig, att, mask, ctx.tab, grad_out.contiguous(), ctx.net)
+        return g.to(att.device), None, None, None, None
+
+
+def _chw3(t):
+    t = torch.as_tensor(t, dtype=torch.float32)
+    return t[0] if t.dim() == 4 else t
+
+
+def transform_wb_batch(orig, att, mask, transforms, pt_file='inputs/GTSRB/Points/14.csv', net_size=32):
+    """All transforms of one (orig, att, mask) in one launch: [T,3,32,32] on the GPU, values in [0,1];
+    gradients flow to `att` (one backward launch for all T).  `transforms` is the list from get_transform_params
+    or a table from build_wb_table."""
+    if net_size != 32:
+        raise NotImplementedError("only the net_size == 32 branch of convert2NetworkWB is implemented")
+    from . import _hip
+    o, a, m = _chw3(orig), _chw3(att), _chw3(mask)
+    if isinstance(transforms, np.ndarray) and transforms.dtype == _hip.WB_XFORM_DTYPE:
+        tab = transforms
+    else:
+        tab = build_wb_table(transforms, o.shape[2], o.shape[1], pt_file)
+    if (tab["crop_x"] != tab["crop_y"]).any():
+        raise NotImplementedError("non-square crops (ALPR) are outside this path")
+    dev = _hip.to_dev(o).device
+    return _TransformWB.apply(a.to(dev), o.to(dev), m.to(dev).float(), tab, net_size)
+
+
+def transform_wb(orig, att, mask, transform, pt_file='inputs/GTSRB/Points/14.csv', net_size=32):
+    """Reference signature (:176): orig, att [1,3,H,W]; mask [3,H,W]; one transform tuple -> [1,3,32,32] in [0,1]."""
+    return transform_wb_batch(orig, att, mask, [transform], pt_file, net_size)
+
+
+def convert2NetworkWB(img, is_torch=True, net_size=32):
+    """kornia resize(img, 32, align_corners=False) + clamp (:209-214) for a [B,3,H,W] or [3,H,W] tensor.
+    Stand-alone use only (the baselines); inside transform_wb the resize is fused into the HIP kernel.  This helper
+    is plain torch (F.interpolate), on whatever device `img` lives."""
+    if net_size != 32:
+        raise NotImplementedError("only the net_size == 32 branch of convert2NetworkWB is implemented")
+    x = img if img.dim() == 4 else img[None]
+    y = torch.clamp(torch.nn.functional.interpolate(x, size=(32, 32), mode='bilinear', align_corners=False), 0.0, 1.0)
+    return y if img.dim() == 4 else y[0]

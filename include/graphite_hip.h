@@ -134,6 +134,33 @@ int gr_tr_hits(gr_ctx* ctx, gr_model* m, const float* img, int H, int W, const f
                int C, int nh, int nw, const gr_xforms* xf, float lbd, int normalize, int target, int64_t img_begin,
                int64_t img_count, int32_t* hits, int64_t* preds, float* logits, void* stream);
 
+/* ---- differentiable ("whitebox") transform, forward and backward ------------
+ * transform_wb (transforms.py:176-207) for T transforms of ONE (orig, att, mask) at once:
+ *   clamp(att) -> [depthwise Gaussian conv, zero padded, of the masked perturbation] -> where(mask) -> clamp ->
+ *   kornia warp_perspective(align_corners=True, padding_mode='border') (perspective_transform.py:49) ->
+ *   adjust_gamma -> resize(net, align_corners=False) -> clamp                       (all float32)
+ * One descriptor per transform, prepared on the host as kornia's normalize_homography does:
+ *   A      float32 3x3 mapping NORMALISED dst coordinates to NORMALISED src coordinates
+ *          (inverse of N_dst * M * inv(N_src), in float32)
+ *   crop   (crop_x, crop_y) = dsize of the warp (both > 1); gamma; blur in {0,3,5,7}.
+ * orig, att, mask: [3,H,W] float32 dev (mask 0/1).  xf: HOST array of T descriptors (copied per call;
+ * the call synchronises the stream once for that copy).
+ * gr_wb_forward : out      [T,3,net,net] dev, values in [0,1] (the caller subtracts 0.5 for GTSRB, whitebox_attack.py:155).
+ * gr_wb_backward: grad_out [T,3,net,net] dev = d loss / d out for all T; grad_att [3,H,W] dev (overwritten) =
+ *                 d loss / d att summed over the T transforms (the EOT loop averages it, whitebox_attack.py:159-162).
+ *                 Accumulation uses float atomics: the summation order, hence the last bits, vary between runs.
+ *                 pow's derivative at att == 0 follows IEEE (inf / nan for gamma < 1), as torch's does. */
+typedef struct gr_wb_xform {
+    float A[9];
+    int32_t crop_x, crop_y;
+    float gamma;
+    int32_t blur;
+} gr_wb_xform;
+int gr_wb_forward(gr_ctx* ctx, const float* orig, const float* att, const float* mask, int H, int W,
+                  const gr_wb_xform* xf, int T, int net, float* out, void* stream);
+int gr_wb_backward(gr_ctx* ctx, const float* orig, const float* att, const float* mask, int H, int W,
+                   const gr_wb_xform* xf, int T, int net, const float* grad_out, float* grad_att, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

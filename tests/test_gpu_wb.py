@@ -1,0 +1,109 @@
+"""GPU parity of the differentiable ("whitebox") transform: HIP forward and backward kernels, through
+the C ABI, against the plain-PyTorch fp32 restatement oracle/wb_reference.py (forward values and autograd gradients).
+
+Tolerances (floating point; kornia's internals are restated, parity unpinned): forward 2e-6 absolute on [0,1] pixels;
+gradients 1e-5 of the largest |gradient| per element (float atomics reorder the sums; powf differs by an ulp or two)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
+import wb_reference as R                                                   # noqa: E402
+from cases import PT14, gtsrb_case                                          # noqa: E402
+from graphite_amd import _hip, transforms as T                              # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+FWD_TOL = 2e-6          # measured 3e-7
+GRAD_TOL = 1e-5         # measured 4.5e-7 of the largest |gradient|
+
+
+def _scene(seed=0):
+    c = gtsrb_case(num_xforms=24)
+    g = torch.Generator().manual_seed(seed)
+    orig = torch.from_numpy(0.04 + 0.92 * c["vic"])                         # strictly positive: pow'(0) is inf for gamma < 1
+    att = orig + 0.25 * torch.randn(orig.shape, generator=g)
+    att = torch.where(att < 0.03, torch.full_like(att, 0.03), att)          # some values > 1 stay: the clamp's zero gradient
+    mask = torch.zeros(3, 244, 244)
+    mask[:, 40:200, 30:215] = 1.0
+    mask[:, 100:130, 90:150] = 0.0
+    return c, orig, att, mask
+
+
+def _ref_forward(c, orig, att, mask, idx):
+    outs = []
+    for t in idx:
+        tr = c["xf"][t]
+        xf = c["tab"][t]
+        outs.append(R.transform_wb(orig[None], att[None], mask, xf["M"].reshape(3, 3), int(xf["crop_x"]), int(xf["crop_y"]),
+                                   float(tr[2]), int(tr[3])))
+    return torch.cat(outs)
+
+
+def test_wb_forward_matches_torch_reference():
+    c, orig, att, mask = _scene()
+    assert set(int(b) for b in c["tab"]["blur"]) == {0, 3, 5, 7}
+    got = T.transform_wb_batch(orig, att, mask, c["xf"], PT14).cpu()
+    ref = _ref_forward(c, orig, att, mask, range(len(c["xf"])))
+    assert got.shape == ref.shape == (24, 3, 32, 32)
+    assert float((got - ref).abs().max()) <= FWD_TOL
+    # reference signature: one transform, batched [1,3,H,W] inputs
+    one = T.transform_wb(orig[None], att[None], mask, c["xf"][5], PT14).cpu()
+    assert one.shape == (1, 3, 32, 32) and torch.equal(one[0], got[5])
+
+
+def test_wb_backward_matches_torch_autograd():
+    c, orig, att, mask = _scene(1)
+    idx = list(range(24))
+    w = torch.randn(24, 3, 32, 32, generator=torch.Generator().manual_seed(2))
+    a_ref = att.clone().requires_grad_(True)
+    (_ref_forward(c, orig, a_ref, mask, idx) * w).sum().backward()
+    a_gpu = att.clone().requires_grad_(True)
+    out = T.transform_wb_batch(orig, a_gpu, mask, c["xf"], PT14)
+    (out * w.to(out.device)).sum().backward()
+    g_ref, g_gpu = a_ref.grad, a_gpu.grad.cpu()
+    assert torch.isfinite(g_ref).all() and torch.isfinite(g_gpu).all()
+    scale = float(g_ref.abs().max())
+    assert scale > 0
+    assert float((g_gpu - g_ref).abs().max()) <= GRAD_TOL * scale
+    # no gradient outside the mask or where att was clamped from above
+    assert float(g_gpu[mask < 0.5].abs().max()) == 0.0
+    assert float(g_gpu[(att > 1.0)].abs().max()) == 0.0
+    # per-blur-kernel subsets (single composite slot each)
+    for k in (0, 3, 5, 7):
+        sel = [t for t in idx if int(c["tab"][t]["blur"]) == k][:3]
+        a1 = att.clone().requires_grad_(True)
+        _ref_forward(c, orig, a1, mask, sel).sum().backward()
+        a2 = att.clone().requires_grad_(True)
+        T.transform_wb_batch(orig, a2, mask, [c["xf"][t] for t in sel], PT14).sum().backward()
+        s = float(a1.grad.abs().max())
+        assert float((a2.grad.cpu() - a1.grad).abs().max()) <= GRAD_TOL * s, k
+
+
+def test_wb_eot_gradient_step_like_the_reference_loop():
+    """whitebox_attack.py:149-170 in batched form: average gradient of a loss over the transforms, sign step inside the mask."""
+    c, orig, att, mask = _scene(3)
+    a = att.clone().requires_grad_(True)
+    out = T.transform_wb_batch(orig, a, mask, c["xf"], PT14) - 0.5
+    loss = (out ** 2).mean(dim=(1, 2, 3)).sum()
+    g, = torch.autograd.grad(loss, a)
+    avg = (g / len(c["xf"])).cpu()
+    a_ref = att.clone().requires_grad_(True)
+    ref = _ref_forward(c, orig, a_ref, mask, range(24)) - 0.5
+    g_ref, = torch.autograd.grad((ref ** 2).mean(dim=(1, 2, 3)).sum(), a_ref)
+    avg_ref = g_ref / 24
+    big = avg_ref.abs() > 1e-3 * avg_ref.abs().max()
+    assert torch.equal(torch.sign(avg[big]), torch.sign(avg_ref[big]))
+
+
+def test_wb_error_codes():
+    lib, ctx = _hip.load_library(), _hip.ctx()
+    assert lib.gr_wb_forward(ctx, None, None, None, 244, 244, None, 1, 32, None, None) == -1
+    c, orig, att, mask = _scene()
+    tab = T.build_wb_table(c["xf"][:2], 244, 244, PT14)
+    tab["blur"] = 4
+    with pytest.raises(_hip.GraphiteHipError, match="blur"):
+        _hip.wb_forward(orig, att, mask, tab)
