@@ -139,6 +139,19 @@ def extras(_hip, engine, models, synth):
                                     float(g100["xf"][t][2]), int(g100["xf"][t][3])))
     (torch.cat(outs) * gout.cpu()).sum().backward()
     cdt = time.perf_counter() - t0
+    # the whole EOT step with the HIP classifier gradient (transform_wb -> GTSRBNet -> CE -> d/d adv, 100 transforms)
+    wmodel = models.GTSRBNet()
+    wmodel.load_state_dict(synth.gtsrb_state_dict(readout="toy3"))
+    for _ in range(2):
+        engine.eot_gradient(wmodel, od, ad, md, wtab, 27)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(10):
+        engine.eot_gradient(wmodel, od, ad, md, wtab, 27)
+    torch.cuda.synchronize()
+    edt = (time.perf_counter() - t0) / 10
+    res["whitebox_eot_step"] = {"transforms": 100, "ms": 1e3 * edt, "eot_steps_per_s": 1.0 / edt,
+                                "what": "gr_wb_forward + gr_model_input_grad (GTSRBNet forward + transposed layers) + gr_wb_backward"}
     res["whitebox_eot_gradient"] = {
         "transforms": 100, "ms_fwd_plus_bwd": 1e3 * dt, "eot_gradients_per_s": 1.0 / dt,
         "cpu_torch_reference_ms": 1e3 * cdt, "cpu_threads": torch.get_num_threads(),

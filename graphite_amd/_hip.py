@@ -46,6 +46,7 @@ SIGNATURES = {
     "gr_model_num_classes": (_i, [_vp]),
     "gr_model_forward": (_i, [_vp, _vp, _vp, _i, _vp, _vp]),
     "gr_model_predict": (_i, [_vp, _vp, _vp, _i, _vp, _vp]),
+    "gr_model_input_grad": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp, _vp]),
     "gr_tr_hits": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp, _i, _i, _i, _vp, _f, _i, _i, _i64, _i64, _vp, _vp, _vp, _vp]),
     "gr_wb_forward": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp, _i, _i, _vp, _vp]),
     "gr_wb_backward": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp, _i, _i, _vp, _vp, _vp]),
@@ -282,6 +283,18 @@ class Model:
         h, self._h = getattr(self, "_h", None), None
         if h and _lib is not None:
             _lib.gr_model_destroy(h)
+
+    def input_grad(self, x, target):
+        """(logits [N,ncls], d CE(logits_n, target) / d x_n [N,3,32,32]) as CUDA tensors; GTSRBNet only."""
+        xd = to_dev(x)
+        if xd.dim() == 3:
+            xd = xd[None]
+        n = xd.shape[0]
+        logits = torch.empty((n, self.num_classes), device=xd.device, dtype=torch.float32)
+        gx = torch.empty_like(xd)
+        _check(self._ctx, load_library().gr_model_input_grad(self._ctx, self._h, _p(xd), n, int(target), _p(logits), _p(gx),
+                                                             _stream()), "gr_model_input_grad")
+        return logits, gx
 
     def forward(self, x):
         """x: [N,3,32,32] (any device) -> logits CUDA tensor [N,ncls]."""

@@ -325,6 +325,24 @@ extern "C" int gr_model_predict(gr_ctx* ctx, gr_model* m, const float* x, int N,
     return GR_OK;
 }
 
+extern "C" int gr_model_input_grad(gr_ctx* ctx, gr_model* m, const float* x, int N, int target, float* logits,
+                                   float* grad_x, void* stream) {
+    NEED_CTX();
+    if (!m || !x || !grad_x || N < 0) return gr_fail(ctx, GR_EINVAL, "gr_model_input_grad: bad arguments");
+    hipStream_t st = (hipStream_t)stream;
+    const int ncls = gr_model_num_classes(m);
+    int chunk = N < 1024 ? N : 1024;                  // the pass keeps ~0.8 MB of activations per image
+    if (chunk <= 0) return GR_OK;
+    int rc = gr_ws_reserve(ctx, net_grad_workspace_bytes(m, chunk), stream);
+    if (rc) return rc;
+    for (int n0 = 0; n0 < N; n0 += chunk) {
+        int nb = N - n0 < chunk ? N - n0 : chunk;
+        if ((rc = net_input_grad(ctx, m, x + (size_t)n0 * 3072, nb, target, logits ? logits + (size_t)n0 * ncls : nullptr,
+                                 grad_x + (size_t)n0 * 3072, ctx->ws, ctx->ws_bytes, st))) return rc;
+    }
+    return GR_OK;
+}
+
 // ---------------------------------------------------------------------------------------------
 // fused TR evaluation
 // ---------------------------------------------------------------------------------------------

@@ -83,3 +83,7 @@ size_t net_workspace_bytes(const gr_model*, int N);
 int net_argmax(gr_ctx*, const float* logits, int N, int ncls, int64_t* preds, hipStream_t);
 int net_hits(gr_ctx*, const float* logits, int N, int ncls, int64_t n_begin, int T, int target, int32_t* hits,
              int64_t* preds, hipStream_t);
+// d CE(logits_n, target) / d x_n (GTSRBNet): forward with every activation kept, then the transposed layers
+int net_input_grad(gr_ctx*, gr_model*, const float* x_chw, int N, int target, float* logits_or_null, float* grad_x, char* ws,
+                   size_t ws_bytes, hipStream_t);
+size_t net_grad_workspace_bytes(const gr_model*, int N);

@@ -35,6 +35,7 @@ struct ConvParams {
     int KH, KW, stride, pad;
     int M;                // B*Ho*Wo
     int relu;
+    const float* gate;    // [M,Cout] or null: the output is zeroed where gate <= 0 (ReLU backward of the producer's activation)
     int kchunk;           // 0: k = (ky,kx,ci).  BK: k = (ci/BK, ky, kx, ci%BK) -- the order conv_halo_cc.h walks
 };
 
@@ -226,6 +227,7 @@ __global__ __launch_bounds__(WM* WN * 64) void k_conv_igemm(ConvParams p) {
                         float v = acc[i][j][r] + bias;
                         if (p.res) v = v + p.res[(size_t)m * p.Cout + co];
                         if (p.relu) v = v > 0.f ? v : 0.f;
+                        if (p.gate && !(p.gate[(size_t)m * p.Cout + co] > 0.f)) v = 0.f;
                         if (p.out_raw) p.out_raw[(size_t)m * p.Cout + co] = v;
                         if (p.out_act) {
                             float w = fmaf(v, sc, sh);

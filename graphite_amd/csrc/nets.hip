@@ -37,6 +37,7 @@ struct gr_model {
     // GTSRBNet
     float* c11 = nullptr;    // conv1_1: 9 weights + 3 biases
     Layer g[9];              // conv2_1 .. fc7_1
+    Layer gb[9];             // the same layers transposed (input-gradient pass): conv with flipped taps / W^T
     // WideResNet
     Layer wconv1, wfc;
     std::vector<WrnBlock> blocks;
@@ -144,6 +145,33 @@ extern "C" int gr_model_load_gtsrb(gr_ctx* ctx, const float* const* t, const int
     }
     if (!rc) rc = make_layer(m, &m->g[7], t[16], t[17], 1024, 1024, 1, 1, 1, 0);
     if (!rc) rc = make_layer(m, &m->g[8], t[18], t[19], 43, 1024, 1, 1, 1, 0);
+    // transposed layers for gr_model_input_grad: dX = conv(dY, W') with W'[ci][co][ky][kx] = W[co][ci][4-ky][4-kx]
+    for (int l = 1; l <= 6 && !rc; l++) {
+        std::vector<float> wt((size_t)co[l] * ci[l] * 25);
+        for (int o = 0; o < co[l]; o++)
+            for (int i = 0; i < ci[l]; i++)
+                for (int k = 0; k < 25; k++) wt[((size_t)i * co[l] + o) * 25 + (24 - k)] = t[2 * l][((size_t)o * ci[l] + i) * 25 + k];
+        rc = make_layer(m, &m->gb[l - 1], wt.data(), nullptr, ci[l], co[l], 5, 5, 1, 2);
+    }
+    if (!rc) {      // fc5^T: output index in NHWC-flatten order, as the activations are laid out
+        std::vector<float> wt((size_t)2048 * 1024);
+        for (int o = 0; o < 1024; o++)
+            for (int c = 0; c < 128; c++)
+                for (int sp = 0; sp < 16; sp++) wt[(size_t)(sp * 128 + c) * 1024 + o] = t[14][(size_t)o * 2048 + c * 16 + sp];
+        rc = make_layer(m, &m->gb[6], wt.data(), nullptr, 2048, 1024, 1, 1, 1, 0);
+    }
+    if (!rc) {
+        std::vector<float> wt((size_t)1024 * 1024);
+        for (int o = 0; o < 1024; o++)
+            for (int i = 0; i < 1024; i++) wt[(size_t)i * 1024 + o] = t[16][(size_t)o * 1024 + i];
+        rc = make_layer(m, &m->gb[7], wt.data(), nullptr, 1024, 1024, 1, 1, 1, 0);
+    }
+    if (!rc) {      // fc7^T with the 43 logit gradients padded to 64 input channels
+        std::vector<float> wt((size_t)1024 * 64, 0.f);
+        for (int o = 0; o < 43; o++)
+            for (int i = 0; i < 1024; i++) wt[(size_t)i * 64 + o] = t[18][(size_t)o * 1024 + i];
+        rc = make_layer(m, &m->gb[8], wt.data(), nullptr, 1024, 64, 1, 1, 1, 0);
+    }
     if (rc) { gr_model_destroy(m); return rc; }
     *out = m;
     return GR_OK;
@@ -293,9 +321,9 @@ static bool use_igemm_convs();
 static int halo_variant(int layer);
 
 static int run_conv(gr_ctx* ctx, const Layer& L, const float* in, int B, int H, int W, const float* res, const BnDev* act,
-                    float* out_raw, float* out_act, bool relu, bool pool, hipStream_t st) {
+                    float* out_raw, float* out_act, bool relu, bool pool, hipStream_t st, const float* gate = nullptr) {
     ConvParams p;
-    p.in = in; p.wgt = L.w; p.bias = L.bias; p.res = res;
+    p.in = in; p.wgt = L.w; p.bias = L.bias; p.res = res; p.gate = gate;
     p.scale = act ? act->scale : nullptr; p.shift = act ? act->shift : nullptr;
     p.out_raw = out_raw; p.out_act = out_act;
     p.H = H; p.W = W; p.Cin = L.Cin;
@@ -538,6 +566,130 @@ static int wrn_forward(gr_ctx* ctx, gr_model* m, const float* x, int N, float* l
     hipLaunchKernelGGL(k_avgpool, dim3((N * C + 255) / 256), dim3(256), 0, st, o, N, H * H, C, u);
     GR_HIP(ctx, hipGetLastError());
     return run_conv(ctx, m->wfc, u, N, 1, 1, nullptr, nullptr, logits, nullptr, false, false, st);
+}
+
+// ---------------------------------------------------------------------------------------------
+// input gradient of GTSRBNet (the classifier half of the whitebox EOT loop, whitebox_attack.py:155-158)
+// ---------------------------------------------------------------------------------------------
+// 2x2 max-pool of an NHWC tensor [N,H,W,C] -> [N,H/2,W/2,C]
+__global__ void k_maxpool2_fwd(const float* __restrict__ in, int N, int H, int W, int C, float* __restrict__ out) {
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int Hp = H >> 1, Wp = W >> 1;
+    if (idx >= (size_t)N * Hp * Wp * C) return;
+    const int c = (int)(idx % C);
+    size_t r = idx / C;
+    const int px = (int)(r % Wp); r /= Wp;
+    const int py = (int)(r % Hp);
+    const int n = (int)(r / Hp);
+    const float* s = in + (((size_t)n * H + 2 * py) * W + 2 * px) * C + c;
+    const float v0 = s[0], v1 = s[C], v2 = s[(size_t)W * C], v3 = s[(size_t)W * C + C];
+    float mx = v0 > v1 ? v0 : v1;
+    mx = mx > v2 ? mx : v2;
+    out[idx] = mx > v3 ? mx : v3;
+}
+// backward of relu -> max-pool: d_pre[pixel] = d_pool[window] for the FIRST pixel of the window (row-major scan, as
+// torch's max_pool2d picks) whose activation equals the window maximum, and only where that activation is > 0 (ReLU)
+__global__ void k_maxpool2_relu_bwd(const float* __restrict__ act, const float* __restrict__ gpool, int N, int H, int W, int C,
+                                    float* __restrict__ gpre) {
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int Hp = H >> 1, Wp = W >> 1;
+    if (idx >= (size_t)N * Hp * Wp * C) return;
+    const int c = (int)(idx % C);
+    size_t r = idx / C;
+    const int px = (int)(r % Wp); r /= Wp;
+    const int py = (int)(r % Hp);
+    const int n = (int)(r / Hp);
+    const size_t base = (((size_t)n * H + 2 * py) * W + 2 * px) * C + c;
+    const size_t off[4] = {0, (size_t)C, (size_t)W * C, (size_t)W * C + C};
+    float v[4];
+    for (int k = 0; k < 4; k++) v[k] = act[base + off[k]];
+    int best = 0;
+    for (int k = 1; k < 4; k++)
+        if (v[k] > v[best]) best = k;
+    const float g = v[best] > 0.f ? gpool[idx] : 0.f;
+    for (int k = 0; k < 4; k++) gpre[base + off[k]] = k == best ? g : 0.f;
+}
+// d CE(logits, target) / d logits = softmax(logits) - onehot(target), written into a 64-wide row (zero padded)
+__global__ void k_ce_grad(const float* __restrict__ logits, int N, int ncls, int target, float* __restrict__ g64) {
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    const float* l = logits + (size_t)n * ncls;
+    float mx = l[0];
+    for (int c = 1; c < ncls; c++) mx = l[c] > mx ? l[c] : mx;
+    float sum = 0.f;
+    for (int c = 0; c < ncls; c++) sum += expf(l[c] - mx);
+    float* g = g64 + (size_t)n * 64;
+    for (int c = 0; c < 64; c++) g[c] = c < ncls ? expf(l[c] - mx) / sum - (c == target ? 1.f : 0.f) : 0.f;
+}
+// backward of k_input_nhwc4<true>: ReLU gate on the stored conv1_1 output, 3x3 transpose, NHWC3 -> CHW
+__global__ void k_input_grad(const float* __restrict__ g3, const float4* __restrict__ x4, const float* __restrict__ c11, int N,
+                             float* __restrict__ gx) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= N * 1024) return;
+    const int n = idx >> 10, p = idx & 1023;
+    const float4 a = x4[idx];
+    const float* g = g3 + (size_t)idx * 3;
+    const float r0 = a.x > 0.f ? g[0] : 0.f, r1 = a.y > 0.f ? g[1] : 0.f, r2 = a.z > 0.f ? g[2] : 0.f;
+    float* o = gx + (size_t)n * 3072 + p;
+#pragma unroll
+    for (int i = 0; i < 3; i++) o[i * 1024] = r0 * c11[0 * 3 + i] + r1 * c11[1 * 3 + i] + r2 * c11[2 * 3 + i];
+}
+
+static size_t grad_floats_per_image() {
+    //     x4     a21     a22     p2     a31     a32     p3     a41    a42    p4     f5     f6    lg   g64   gA      gB
+    return 4096 + 32768 + 32768 + 8192 + 16384 + 16384 + 4096 + 8192 + 8192 + 2048 + 1024 + 1024 + 64 + 64 + 32768 + 32768;
+}
+size_t net_grad_workspace_bytes(const gr_model* m, int N) {
+    (void)m;
+    return gr_align(grad_floats_per_image() * sizeof(float) * (size_t)N);
+}
+
+// logits (optional) and d CE(logits_n, target) / d x_n for N images; GTSRBNet only.
+int net_input_grad(gr_ctx* ctx, gr_model* m, const float* x, int N, int target, float* logits_out, float* gx, char* wsb,
+                   size_t ws_bytes, hipStream_t st) {
+    if (N <= 0) return GR_OK;
+    if (m->kind != 1) return gr_fail(ctx, GR_EINVAL, "input gradients are implemented for GTSRBNet only");
+    if (target < 0 || target >= m->ncls) return gr_fail(ctx, GR_EINVAL, "target %d out of range", target);
+    if (ws_bytes < net_grad_workspace_bytes(m, N)) return gr_fail(ctx, GR_ESTATE, "net_input_grad: workspace too small");
+    float* w = (float*)wsb;
+    auto take = [&](size_t per) { float* p = w; w += per * (size_t)N; return p; };
+    float *x4 = take(4096), *a21 = take(32768), *a22 = take(32768), *p2 = take(8192), *a31 = take(16384), *a32 = take(16384);
+    float *p3 = take(4096), *a41 = take(8192), *a42 = take(8192), *p4 = take(2048), *f5 = take(1024), *f6 = take(1024);
+    float *lg = take(64), *g64 = take(64), *gA = take(32768), *gB = take(32768);
+    auto blocks = [](size_t n) { return dim3((unsigned)((n + 255) / 256)); };
+    int rc;
+    // ---- forward, keeping every activation (pool layers un-fused so that the arg-max is recoverable) ----
+    hipLaunchKernelGGL(k_input_nhwc4<true>, blocks((size_t)N * 1024), dim3(256), 0, st, x, m->c11, N, (float4*)x4);
+    if ((rc = run_conv(ctx, m->g[0], x4, N, 32, 32, nullptr, nullptr, a21, nullptr, true, false, st))) return rc;
+    if ((rc = run_conv(ctx, m->g[1], a21, N, 32, 32, nullptr, nullptr, a22, nullptr, true, false, st))) return rc;
+    hipLaunchKernelGGL(k_maxpool2_fwd, blocks((size_t)N * 8192), dim3(256), 0, st, a22, N, 32, 32, 32, p2);
+    if ((rc = run_conv(ctx, m->g[2], p2, N, 16, 16, nullptr, nullptr, a31, nullptr, true, false, st))) return rc;
+    if ((rc = run_conv(ctx, m->g[3], a31, N, 16, 16, nullptr, nullptr, a32, nullptr, true, false, st))) return rc;
+    hipLaunchKernelGGL(k_maxpool2_fwd, blocks((size_t)N * 4096), dim3(256), 0, st, a32, N, 16, 16, 64, p3);
+    if ((rc = run_conv(ctx, m->g[4], p3, N, 8, 8, nullptr, nullptr, a41, nullptr, true, false, st))) return rc;
+    if ((rc = run_conv(ctx, m->g[5], a41, N, 8, 8, nullptr, nullptr, a42, nullptr, true, false, st))) return rc;
+    hipLaunchKernelGGL(k_maxpool2_fwd, blocks((size_t)N * 2048), dim3(256), 0, st, a42, N, 8, 8, 128, p4);
+    if ((rc = run_conv(ctx, m->g[6], p4, N, 1, 1, nullptr, nullptr, f5, nullptr, true, false, st))) return rc;
+    if ((rc = run_conv(ctx, m->g[7], f5, N, 1, 1, nullptr, nullptr, f6, nullptr, true, false, st))) return rc;
+    float* lgp = logits_out ? logits_out : lg;
+    if ((rc = run_conv(ctx, m->g[8], f6, N, 1, 1, nullptr, nullptr, lgp, nullptr, false, false, st))) return rc;
+    // ---- backward: every transposed layer gates its output with the ReLU of the activation it produces the gradient of ----
+    hipLaunchKernelGGL(k_ce_grad, blocks((size_t)N), dim3(256), 0, st, lgp, N, m->ncls, target, g64);
+    if ((rc = run_conv(ctx, m->gb[8], g64, N, 1, 1, nullptr, nullptr, gA, nullptr, false, false, st, f6))) return rc;   // d f6
+    if ((rc = run_conv(ctx, m->gb[7], gA, N, 1, 1, nullptr, nullptr, gB, nullptr, false, false, st, f5))) return rc;    // d f5
+    if ((rc = run_conv(ctx, m->gb[6], gB, N, 1, 1, nullptr, nullptr, gA, nullptr, false, false, st))) return rc;        // d p4
+    hipLaunchKernelGGL(k_maxpool2_relu_bwd, blocks((size_t)N * 2048), dim3(256), 0, st, a42, gA, N, 8, 8, 128, gB);      // d a42
+    if ((rc = run_conv(ctx, m->gb[5], gB, N, 8, 8, nullptr, nullptr, gA, nullptr, false, false, st, a41))) return rc;    // d a41
+    if ((rc = run_conv(ctx, m->gb[4], gA, N, 8, 8, nullptr, nullptr, gB, nullptr, false, false, st))) return rc;         // d p3
+    hipLaunchKernelGGL(k_maxpool2_relu_bwd, blocks((size_t)N * 4096), dim3(256), 0, st, a32, gB, N, 16, 16, 64, gA);     // d a32
+    if ((rc = run_conv(ctx, m->gb[3], gA, N, 16, 16, nullptr, nullptr, gB, nullptr, false, false, st, a31))) return rc;  // d a31
+    if ((rc = run_conv(ctx, m->gb[2], gB, N, 16, 16, nullptr, nullptr, gA, nullptr, false, false, st))) return rc;       // d p2
+    hipLaunchKernelGGL(k_maxpool2_relu_bwd, blocks((size_t)N * 8192), dim3(256), 0, st, a22, gA, N, 32, 32, 32, gB);     // d a22
+    if ((rc = run_conv(ctx, m->gb[1], gB, N, 32, 32, nullptr, nullptr, gA, nullptr, false, false, st, a21))) return rc;  // d a21
+    if ((rc = run_conv(ctx, m->gb[0], gA, N, 32, 32, nullptr, nullptr, gB, nullptr, false, false, st))) return rc;       // d x4 [M,3]
+    hipLaunchKernelGGL(k_input_grad, blocks((size_t)N * 1024), dim3(256), 0, st, gB, (const float4*)x4, m->c11, N, gx);
+    GR_HIP(ctx, hipGetLastError());
+    return GR_OK;
 }
 
 int net_forward(gr_ctx* ctx, gr_model* m, const float* x, int N, float* logits, char* ws, size_t ws_bytes, hipStream_t st) {

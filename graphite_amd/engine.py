@@ -92,3 +92,24 @@ def tr_error_rates(model, image, masks, thetas, transforms, target, **kw):
     hits = tr_hits(model, image, masks, thetas, transforms, target, **kw).cpu().numpy()
     T = len(transforms) if not isinstance(transforms, _hip.XformTable) else transforms.T
     return [(1.0 - int(h) * 1.0 / T, T) for h in hits]
+
+
+def eot_gradient(model, image, adv, mask, transforms, target, pt_file='inputs/GTSRB/Points/14.csv', normalize=True):
+    """One step of the whitebox EOT loop (reference whitebox/whitebox_attack.py:149-162), everything on the GPU:
+    x_t = transform_wb(image, adv, mask, transform_t) [- 0.5]; loss_t = CrossEntropy(model(x_t), target);
+    returns (mean over t of d loss_t / d adv  [3,H,W] CUDA, logits [T,ncls] CUDA).
+    Three launches groups: gr_wb_forward, gr_model_input_grad, gr_wb_backward."""
+    import torch
+    from . import transforms as T
+    hip_model = getattr(model, "hip_model", model)
+    o, a, m = _hip.to_dev(T._chw3(image)), _hip.to_dev(T._chw3(adv)), _hip.to_dev(T._chw3(mask))
+    if isinstance(transforms, np.ndarray) and transforms.dtype == _hip.WB_XFORM_DTYPE:
+        tab = transforms
+    else:
+        tab = T.build_wb_table(transforms, o.shape[2], o.shape[1], pt_file)
+    x = _hip.wb_forward(o, a, m, tab)
+    if normalize:
+        x = x - 0.5
+    logits, gx = hip_model.input_grad(x, target)
+    g = _hip.wb_backward(o, a, m, tab, gx)
+    return g / float(len(tab)), logits

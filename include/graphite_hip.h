@@ -122,6 +122,14 @@ int gr_model_forward(gr_ctx* ctx, gr_model* m, const float* x, int N, float* log
 /* predict(): torch.max(logits,1) first-maximum rule (GTSRBNet.py:66) -> preds [N] int64 dev. */
 int gr_model_predict(gr_ctx* ctx, gr_model* m, const float* x, int N, int64_t* preds, void* stream);
 
+/* Input gradient of the classifier for the whitebox EOT loop (whitebox_attack.py:155-158:
+ * logits = model(x); loss = CrossEntropyLoss(logits, target); grad = autograd.grad(loss, x)), GTSRBNet only:
+ * grad_x [N,3,32,32] dev = d CE(logits_n, target) / d x_n PER IMAGE (no averaging over N); logits [N,43] dev optional.
+ * Forward with every activation kept (GTSRBNet.py:35-52), then the transposed layers on the same MFMA kernels
+ * (flipped 5x5 taps, W^T), ReLU / max-pool routing as torch's autograd does (first maximum of a window). */
+int gr_model_input_grad(gr_ctx* ctx, gr_model* m, const float* x, int N, int target, float* logits, float* grad_x,
+                        void* stream);
+
 /* ---- fused TR evaluation --------------------------------------------------------------------
  * run_predictions(get_transformed_images(...)) for C candidates at once (utils.py:29-57):
  * hits[c] = #{t : argmax(model(image(c,t))) == target}.  hits = int32[C] dev (overwritten).
