@@ -167,3 +167,31 @@ def test_eot_gradient_end_to_end():
     assert rel_l2 <= 2e-2, rel_l2
     big = g_ref.abs() > 5e-2 * float(g_ref.abs().max())
     assert float((torch.sign(gc[big]) == torch.sign(g_ref[big])).float().mean()) >= 0.995   # the attack's sign step agrees
+
+
+def test_whitebox_attack_loop_runs_and_shrinks_the_mask():
+    """The whitebox driver (reference whitebox/whitebox_attack.py) end to end on the GPU with the 3-sign classifier:
+    stop sign -> pedestrians.  No reference run exists to pin the trajectory (kornia / cv2 / checkpoint are absent), so the
+    test checks the loop's contract: rounds succeed at >= min_tr, four patches leave the mask per round, query accounting."""
+    import random
+    from cases import INP
+    from graphite_amd.imageio import load_image_chw, load_image_u8_hwc, resize_u8_linear
+    from graphite_amd.whitebox_attack import whitebox_attack, wb_transform_robustness
+    m, _ = _toy_model()
+    img = torch.from_numpy(load_image_chw(os.path.join(INP, "GTSRB/images/14.png")))
+    hull = resize_u8_linear(load_image_u8_hwc(os.path.join(INP, "GTSRB/Hulls/14.png")), 244, 244)
+    mask = torch.from_numpy((np.where(hull > 128, 255, 0).transpose(2, 0, 1) / 255.0).astype(np.float32))
+    np.random.seed(42); torch.manual_seed(42); random.seed(42)
+    xforms = T.get_transform_params(20, 'GTSRB')
+    tab = T.build_wb_table(xforms, 244, 244, PT14)
+    assert wb_transform_robustness(m, img, img, mask, tab, 27) == 0.0        # the clean stop sign is never "pedestrians"
+    r = whitebox_attack(m, img, mask, 27, PT14, step_size=4 / 255, iters=20, min_tr=0.6, first_round_iters=60, max_rounds=3,
+                        xforms=xforms)
+    assert r["rounds"] >= 1 and r["transform_robustness"] >= 0.6
+    assert r["mask_size"] < int(mask[0].sum()) and float((r["mask"].cpu() - mask).max()) <= 0      # only ever shrinks
+    assert all(len(h["removed"]) == 4 for h in r["history"])
+    assert r["queries"] % 40 == 0 and r["queries"] >= 40 * r["rounds"]       # T gradient + T evaluation queries per iteration
+    adv = r["adversarial"]
+    assert float(adv.min()) >= 0 and float(adv.max()) <= 1
+    outside = (mask < 0.5)
+    assert torch.equal(adv.cpu()[outside], img[outside])                      # nothing changes outside the starting mask
