@@ -27,7 +27,8 @@ from .evaluator import TREvaluator, make_evaluator
 from .transforms import get_transform_params
 
 scoremod = None
-FINE_WINDOW = 16          # speculative candidates per launch in the fine reduction
+FINE_WINDOW = 32          # largest speculative window (candidates per launch) in the fine reduction
+FINE_WINDOW_MIN = 4       # the window doubles after a fully consumed launch and halves after a mis-speculation
 
 
 def _load_scoremod(scorefile):
@@ -161,6 +162,7 @@ def get_fine_reduced_mask(start_mask, object_size, patches, indices, img_v, img_
     best_tr, best_mask = init_tr, start_mask
     ones = torch.ones(start_mask.size())
     last_accept = True                                   # first window speculates an accept chain
+    win = max(1, min(FINE_WINDOW, 2 * FINE_WINDOW_MIN))
 
     done = False
     while patches and not done:
@@ -168,7 +170,7 @@ def get_fine_reduced_mask(start_mask, object_size, patches, indices, img_v, img_
         spec_mask = best_mask
         window = []                                      # (position in list, patch, index, candidate mask, assumed base)
         pos = len(patches)
-        while pos > 0 and len(window) < FINE_WINDOW:
+        while pos > 0 and len(window) < win:
             pos -= 1
             p = patches[pos]
             if torch.max(p * spec_mask) == 0:            # the reference would skip it (given the assumed outcomes)
@@ -205,6 +207,7 @@ def get_fine_reduced_mask(start_mask, object_size, patches, indices, img_v, img_
             last_accept = accepted
             if done or mispredicted:
                 break
+        win = min(FINE_WINDOW, 2 * win) if consumed == len(window) else max(min(FINE_WINDOW, FINE_WINDOW_MIN), win // 2)
         del patches[len(patches) - consumed:]
         del indices[len(indices) - consumed:]
     return best_score, best_tr, best_mask, reduction_query_ct
