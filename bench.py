@@ -49,6 +49,21 @@ def host_threads():
 WRN34_10_FLOPS_PER_IMAGE = 13317812736
 
 
+def bench_case(num_xforms, target_id=1):
+    """The stop-sign scene of SURVEY 8d (victim 14.png, target, hull 14, Points/14.csv, seed-42 transforms), prepared with
+    the product's own code only (the 244 -> 32 downsample runs on the GPU): the oracle stays out of the measured path."""
+    from cases import INP, PT14
+    from graphite_amd import _hip, transforms as T
+    from graphite_amd.imageio import load_image_chw
+    vic = load_image_chw(os.path.join(INP, "GTSRB/images/14.png"))
+    tar = load_image_chw(os.path.join(INP, "GTSRB/images/%d.png" % target_id))
+    hull = (load_image_chw(os.path.join(INP, "GTSRB/Hulls/14.png")) * 255 > 128).astype(np.float32)
+    vic_s, tar_s = _hip.resize_linear(vic, 32, 32), _hip.resize_linear(tar, 32, 32)
+    np.random.seed(42)
+    xf = T.get_transform_params(num_xforms, "GTSRB")
+    return dict(vic=vic, tar_s=tar_s, vic_s=vic_s, hull=hull, xf=xf, tab=T.build_xform_table(xf, 244, 244, PT14), pt_file=PT14)
+
+
 def extras(_hip, engine, models, synth):
     """Secondary measurements, N=1 only; none of them enters `value`.
     config3: CIFAR path (32x32 victim, no outline file, WideResNet-34-10 fp32, seeded synthetic weights):
@@ -111,9 +126,9 @@ def extras(_hip, engine, models, synth):
     # the inner body of whitebox_attack.py:149-162 without the classifier; checked against the torch restatement
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import wb_reference as WR
-    from cases import gtsrb_case as _gc, PT14
+    from cases import PT14
     from graphite_amd import transforms as GT
-    g100 = _gc(num_xforms=100)
+    g100 = bench_case(100)
     gen = torch.Generator().manual_seed(0)
     orig = torch.from_numpy(0.04 + 0.92 * g100["vic"])
     attw = torch.clamp(orig + 0.25 * torch.randn(orig.shape, generator=gen), 0.03, None)
@@ -213,12 +228,11 @@ def main():
         else:
             dist.init_process_group(backend)
 
-    from cases import gtsrb_case
     from graphite_amd import _hip, engine, models, synth
 
     C_total = args.cands_per_gpu * world
     T = args.transforms
-    case = gtsrb_case(num_xforms=T)
+    case = bench_case(T)
     hull = case["hull"]
     masks = synth.synth_patch_masks("bench-sweep", C_total, hull)            # hull x Bernoulli(0.5) 4x4 patches
     thetas = ((case["tar_s"] - case["vic_s"])[None] * masks).astype(np.float32)
