@@ -300,12 +300,15 @@ template <int CIN, int CPH, int KH, int KW, int PS, int TH, int TW, int NIMG, in
 static inline hipError_t launch_conv_halo(const HaloParams& p, hipStream_t st) {
     constexpr size_t smem = sizeof(float) * ((size_t)NIMG * (TH + 4) * ((TW + 4) * PS + 32) + 32);
     auto kern = k_conv_halo<CIN, CPH, KH, KW, PS, TH, TW, NIMG, WM, WN, TM, TN, KU, NP, POOL, PIPE>;
-    static bool attr_set = false;
-    if (!attr_set) {
+    // the attribute is per device: one flag per device this process launches on
+    static bool attr_set[64] = {false};
+    int dev_ = 0;
+    if (hipGetDevice(&dev_) != hipSuccess || dev_ < 0 || dev_ >= 64) return hipErrorInvalidDevice;
+    if (!attr_set[dev_]) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                            (int)smem);
         if (e != hipSuccess) return e;
-        attr_set = true;
+        attr_set[dev_] = true;
     }
     int groups = (p.B + NIMG - 1) / NIMG;
     groups = (groups + 7) / 8 * 8;                // see the blockIdx decode in the kernel

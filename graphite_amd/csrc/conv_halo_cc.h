@@ -288,12 +288,15 @@ static inline hipError_t launch_conv_halo_cc(const HaloCcParams& p, hipStream_t 
     constexpr int RPAD = (RP && XR < 32) ? ((XR - (TWH * (CC + 1)) % 32) + 32) % 32 : 0;
     constexpr size_t smem = sizeof(float) * ((size_t)NIMG * (TH + 2 * (KS / 2)) * (TWH * (CC + 1) + RPAD) + 32);
     auto kern = k_conv_halo_cc<KS, CC, TH, TW, NIMG, WM, WN, TM, TN, KU, RP, MODE>;
-    static bool attr_set = false;
-    if (!attr_set) {
+    // the attribute is per device: one flag per device this process launches on
+    static bool attr_set[64] = {false};
+    int dev_ = 0;
+    if (hipGetDevice(&dev_) != hipSuccess || dev_ < 0 || dev_ >= 64) return hipErrorInvalidDevice;
+    if (!attr_set[dev_]) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                            (int)smem);
         if (e != hipSuccess) return e;
-        attr_set = true;
+        attr_set[dev_] = true;
     }
     if (p.H % TH || p.W % TW || p.Cin % CC || p.NP % (WN * TN * 32) || p.Cout % 4 || (p.out_act && !(p.scale && p.shift)))
         return hipErrorInvalidValue;

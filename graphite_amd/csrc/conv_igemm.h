@@ -244,13 +244,16 @@ template <int BK, int WM, int WN, int TM, int TN, bool POOL>
 static inline hipError_t launch_conv_igemm(const ConvParams& p, hipStream_t st) {
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
     constexpr size_t smem = sizeof(float) * (2 * BM * (BK + 1) + 2 * BK * BN);
-    static bool attr_set = false;
     auto kern = k_conv_igemm<BK, WM, WN, TM, TN, POOL>;
-    if (!attr_set) {
+    // the attribute is per device: one flag per device this process launches on
+    static bool attr_set[64] = {false};
+    int dev_ = 0;
+    if (hipGetDevice(&dev_) != hipSuccess || dev_ < 0 || dev_ >= 64) return hipErrorInvalidDevice;
+    if (!attr_set[dev_]) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                            (int)smem);
         if (e != hipSuccess) return e;
-        attr_set = true;
+        attr_set[dev_] = true;
     }
     dim3 grid((p.M + BM - 1) / BM, p.NP / BN);
     hipLaunchKernelGGL(kern, grid, dim3(WM * WN * 64), smem, st, p);
