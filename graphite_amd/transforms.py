@@ -8,7 +8,9 @@ Reference interface kept (same names, positional order, defaults, return types):
   get_transform_params   transforms.py:80   (+ `patchguard=` selects pg_transforms.py:67-94)
   add_noise              transforms.py:143
   get_transformed_images transforms.py:162
-Added for the batched path: `build_xform_table`, `gamma_table`.
+  transform_wb           transforms.py:176  (differentiable twin; HIP forward + backward behind torch.autograd)
+  convert2NetworkWB      transforms.py:209  (net_size == 32 branch)
+Added for the batched path: `build_xform_table`, `gamma_table`, `build_wb_table`, `transform_wb_batch`.
 
 Host side = parameter sampling (numpy's global legacy RNG, draw order identical
 to the reference so seeded runs pick the same transforms) and the per-transform
