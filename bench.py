@@ -346,7 +346,10 @@ def main():
         out["cpu_baseline"]["single_thread_images_per_s"] = 2 * T / (time.perf_counter() - t1)
 
     if rank == 0 and world == 1 and not args.no_extras:
-        out["other_configs"] = extras(_hip, engine, models, synth)
+        try:            # secondary figures must never cost the headline line
+            out["other_configs"] = extras(_hip, engine, models, synth)
+        except Exception as e:      # noqa: BLE001
+            out["other_configs"] = {"error": "%s: %s" % (type(e).__name__, e)}
 
     if rank == 0:
         print(json.dumps(out), flush=True)
