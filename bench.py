@@ -203,7 +203,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--cands-per-gpu", type=int, default=512)
     ap.add_argument("--transforms", type=int, default=1000)
-    ap.add_argument("--chunk", type=int, default=8192)
+    ap.add_argument("--chunk", type=int, default=32000, help="images per classifier launch (library default 8192); 32000 divides the 512,000-image step into 16 equal launches")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="skip the per-kernel HIP-event timing")
     ap.add_argument("--no-extras", action="store_true",

@@ -43,7 +43,7 @@ def label(k):
 
 
 res = {"note": __doc__.strip().replace("\n", " "), "kernels": {}}
-for wl, images in (("gtsrb", 8192), ("trhits", 8000), ("wrn", 1024)):
+for wl, images in (("gtsrb", 32000), ("trhits", 8000), ("wrn", 1024)):
     fe, wr, sq = load("fetch_" + wl), load("write_" + wl), load("sq_" + wl)
     tcc, tcp = load("tcc_" + wl), load("tcp_" + wl)
     for k in fe:
@@ -51,7 +51,7 @@ for wl, images in (("gtsrb", 8192), ("trhits", 8000), ("wrn", 1024)):
         if not name or (wl == "trhits" and name.startswith("k_conv")):
             continue
         f_kb, w_kb = fe[k].get("FETCH_SIZE", 0.0), wr.get(k, {}).get("WRITE_SIZE", 0.0)
-        e = {"workload": {"gtsrb": "scripts/tune_conv.py 8192", "trhits": "scripts/prof_tr_hits.py (16 x 1000, chunks of 8192 / 7808)",
+        e = {"workload": {"gtsrb": "scripts/tune_conv.py 32000", "trhits": "scripts/prof_tr_hits.py (16 x 1000, chunks of 8192 / 7808)",
                           "wrn": "scripts/tune_wrn.py 1024"}[wl],
              "images_per_launch": images, "fetch_size_kb": f_kb, "write_size_kb": w_kb,
              "hbm_bytes_raw": (f_kb + w_kb) * 1024, "hbm_bytes_corrected": (2 * f_kb + w_kb) * 1024}

@@ -13,9 +13,9 @@ pass() {   # name, counters, program...
   local name=$1 ctr=$2; shift 2
   timeout -s KILL 150 rocprofv3 --pmc $ctr --output-format csv -d $O/$name -o $name -- python3 "$@" > $O/$name.log 2>&1 || { echo "pass $name failed"; return 1; }
 }
-pass fetch_gtsrb "FETCH_SIZE" $R/scripts/tune_conv.py 8192 || exit 2
-pass write_gtsrb "WRITE_SIZE" $R/scripts/tune_conv.py 8192 || exit 3
-pass sq_gtsrb "SQ_BUSY_CYCLES SQ_WAVES SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_VALU_MFMA_BUSY_CYCLES" $R/scripts/tune_conv.py 8192 || echo non-fatal
+pass fetch_gtsrb "FETCH_SIZE" $R/scripts/tune_conv.py 32000 || exit 2
+pass write_gtsrb "WRITE_SIZE" $R/scripts/tune_conv.py 32000 || exit 3
+pass sq_gtsrb "SQ_BUSY_CYCLES SQ_WAVES SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_VALU_MFMA_BUSY_CYCLES" $R/scripts/tune_conv.py 32000 || echo non-fatal
 pass fetch_trhits "FETCH_SIZE" $R/scripts/prof_tr_hits.py || exit 4
 pass write_trhits "WRITE_SIZE" $R/scripts/prof_tr_hits.py || exit 5
 pass tcc_trhits "TCC_HIT_sum TCC_MISS_sum" $R/scripts/prof_tr_hits.py || echo non-fatal

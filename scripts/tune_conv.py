@@ -12,6 +12,7 @@ from graphite_amd import _hip, models, synth
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 8192
 m = models.GTSRBNet()
 m.load_state_dict(synth.gtsrb_state_dict())
+_hip.set_chunk(max(64, N))          # one launch per layer, as bench.py does with --chunk
 x = torch.rand(N, 3, 32, 32, device="cuda") - 0.5
 for _ in range(2):
     m.forward(x)
