@@ -44,6 +44,8 @@ SIGNATURES = {
     "gr_model_load_wrn": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, C.POINTER(_vp)]),
     "gr_model_destroy": (None, [_vp]),
     "gr_model_num_classes": (_i, [_vp]),
+    "gr_model_set_precision": (_i, [_vp, _i]),
+    "gr_model_get_precision": (_i, [_vp]),
     "gr_model_forward": (_i, [_vp, _vp, _vp, _i, _vp, _vp]),
     "gr_model_predict": (_i, [_vp, _vp, _vp, _i, _vp, _vp]),
     "gr_model_input_grad": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp, _vp]),
@@ -283,6 +285,19 @@ class Model:
         h, self._h = getattr(self, "_h", None), None
         if h and _lib is not None:
             _lib.gr_model_destroy(h)
+
+    PRECISIONS = {"f32": 0, "bf16": 1}                    # GR_PREC_F32, GR_PREC_BF16
+
+    def set_precision(self, precision):
+        """'f32' (default; the parity path) or 'bf16' (GTSRBNet conv2_2..conv4_2 on bf16 operands, f32 accumulation)."""
+        if precision not in self.PRECISIONS:
+            raise ValueError(f"precision must be one of {sorted(self.PRECISIONS)}")
+        _check(self._ctx, load_library().gr_model_set_precision(self._h, self.PRECISIONS[precision]), "gr_model_set_precision")
+
+    @property
+    def precision(self):
+        v = int(load_library().gr_model_get_precision(self._h))
+        return {0: "f32", 1: "bf16"}[v]
 
     def input_grad(self, x, target):
         """(logits [N,ncls], d CE(logits_n, target) / d x_n [N,3,32,32]) as CUDA tensors; GTSRBNet only."""

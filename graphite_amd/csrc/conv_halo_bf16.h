@@ -1,0 +1,292 @@
+// conv_halo_bf16.h -- bf16 MFMA convolution for GTSRBNet's stride-1 5x5 convs (the "throughput mode" of the
+// north star: bf16 operands, f32 accumulation).  NOT the parity path: the fp32 kernels of conv_halo.h are.
+//
+// Same data movement idea as conv_halo.h -- the haloed input tile is staged in LDS once per workgroup -- with the
+// operands shaped for v_mfma_f32_32x32x16_bf16 (8 k-values per lane, one ds_read_b128 each):
+//   * A: the tile is converted f32 -> bf16 (round to nearest even) while it is staged; pixel stride CIN*2+16 bytes
+//     (an odd number of 16-byte slots) and a row stride chosen so that the 16-lane groups of ds_read_b128 hit 16
+//     distinct slots for every pixel order used here (linear 16- and 8-wide tiles, 2x2 pool windows).
+//   * B: weights are packed at load as [k-block of 16][32-wide n tile][k half][cout][8 k] bf16, i.e. in the exact
+//     order the lanes read them, and streamed global -> registers -> LDS in stages of KBS k-blocks: two LDS buffers,
+//     one workgroup barrier per stage, and a register ring PF stages deep -- a stage is only 0.2-0.5 us of MFMA work,
+//     well under the L2 latency, so the loads of stage s+PF+1 are issued while stage s is computed (an MFMA here is 16x
+//     faster than the fp32 one, so the weights can no longer come straight from L2 into every wave's registers).
+//     The stream reads stage indices clamped to the last stage instead of branching (conv_halo.h: a conditional
+//     prefetch costs a full vmcnt drain).
+//   * k order: (tap = ky*5+kx, ci); accumulation order inside an MFMA is the hardware's.
+//   * Epilogue as conv_halo.h: + bias, ReLU, optional 2x2 max-pool in registers, f32 NHWC store.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <utility>
+#include "conv_igemm.h"
+
+// compile-time loop: f(integral_constant<int, 0>) ... f(integral_constant<int, N-1>)
+template <int... I, class F>
+__device__ __forceinline__ void bf_static_for_impl(std::integer_sequence<int, I...>, F&& f) {
+    (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, class F>
+__device__ __forceinline__ void bf_static_for(F&& f) {
+    bf_static_for_impl(std::make_integer_sequence<int, N>{}, static_cast<F&&>(f));
+}
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+struct HaloBfParams {
+    const float* in;        // [B,H,W,CIN] f32 NHWC
+    const uint16_t* wgt;    // bf16, [K/16][COUT/32][2][32][8]
+    const float* bias;      // [COUT]
+    float* out;             // [B,H,W,COUT] or pooled [B,H/2,W/2,COUT], f32
+    int B, H, W, relu;
+};
+
+// geometry shared by the kernel and its launcher
+template <int CIN, int COUT, int TH, int TW, int NIMG, int KBS, bool POOL>
+struct HaloBfGeom {
+    static constexpr int THH = TH + 4, TWH = TW + 4;
+    static constexpr int PSB = CIN * 2 + 16;                       // bytes per pixel
+    static constexpr int RWANT = (POOL || TW == 8) ? 8 : 0;        // row stride in 16-byte slots, mod 16
+    static constexpr int RS0 = TWH * PSB;
+    static constexpr int RSB = RS0 + ((RWANT - (RS0 / 16) % 16 + 16) % 16) * 16;
+    static constexpr int IMGB = THH * RSB;
+    static constexpr int A_BYTES = NIMG * IMGB;
+    static constexpr int NTILE = COUT / 32;
+    static constexpr int STAGE_B = KBS * NTILE * 1024;
+    static constexpr int LDS_BYTES = A_BYTES + 2 * STAGE_B;
+};
+
+template <int CIN, int COUT, int TH, int TW, int NIMG, int WM, int WN, int TM, int TN, int KBS, bool POOL, int PF>
+__global__ __launch_bounds__(WM* WN * 64) void k_conv_halo_bf16(HaloBfParams p) {
+    using G = HaloBfGeom<CIN, COUT, TH, TW, NIMG, KBS, POOL>;
+    constexpr int NT = WM * WN * 64;
+    constexpr int THH = G::THH, TWH = G::TWH, PSB = G::PSB, RSB = G::RSB, IMGB = G::IMGB;
+    constexpr int NTILE = G::NTILE, STAGE_B = G::STAGE_B;
+    constexpr int KB_TAP = CIN / 16;                    // k-blocks per tap
+    constexpr int NKB = 25 * KB_TAP;
+    constexpr int NS = NKB / KBS;                        // stages
+    constexpr int SV = STAGE_B / 16;                     // 16-byte vectors per stage
+    constexpr int VPT = (SV + NT - 1) / NT;
+    constexpr int MT = NIMG * TH * TW / 32;
+    static_assert(MT == WM * TM, "m tiling");
+    static_assert(NTILE == WN * TN, "n tiling");
+    static_assert(CIN % 16 == 0 && COUT % 32 == 0, "channels");
+    static_assert(NKB % KBS == 0 && (KBS % KB_TAP == 0 || KB_TAP % KBS == 0), "stage size");
+    static_assert((PSB / 16) % 2 == 1, "pixel stride must be an odd number of 16-byte slots");
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_bf[];
+    unsigned char* asm_ = smem_bf;
+    unsigned char* bsm = smem_bf + G::A_BYTES;
+
+    const int tid = threadIdx.x;
+    const int wave = tid >> 6, lane = tid & 63;
+    const int wm = wave / WN, wn = wave % WN;
+    const int lp = lane & 31, lh = lane >> 5;
+    const int tiles_x = p.W / TW, tiles_y = p.H / TH;
+    int bid;                                             // XCD-aware tile order, as conv_halo.h
+    {
+        const int tpi = tiles_x * tiles_y, groups = (p.B + NIMG - 1) / NIMG;
+        const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+        const int g = (j / tpi) * 8 + xcd;
+        if (g >= groups) return;
+        bid = g * tpi + j % tpi;
+    }
+    const int tx = bid % tiles_x; bid /= tiles_x;
+    const int ty = bid % tiles_y; bid /= tiles_y;
+    const int b0 = bid * NIMG;
+    const int y0 = ty * TH, x0 = tx * TW;
+
+    // ---- weight stage 0 on its way while the tile is staged ----
+    const u32x4* wg = reinterpret_cast<const u32x4*>(p.wgt);
+    u32x4 breg[PF + 1][VPT];                            // slot s % (PF+1) holds stage s
+    auto gload = [&](u32x4 (&br)[VPT], int s) {
+        const u32x4* src = wg + (size_t)(s < NS ? s : NS - 1) * SV;
+#pragma unroll
+        for (int v = 0; v < VPT; v++) {
+            const int idx = tid + v * NT;
+            br[v] = src[(SV % NT == 0 || idx < SV) ? idx : SV - 1];
+        }
+    };
+    auto lstore = [&](const u32x4 (&br)[VPT], int buf) {
+#pragma unroll
+        for (int v = 0; v < VPT; v++) {
+            const int idx = tid + v * NT;
+            if (SV % NT == 0 || idx < SV) *reinterpret_cast<u32x4*>(bsm + buf * STAGE_B + idx * 16) = br[v];
+        }
+    };
+#pragma unroll
+    for (int d = 0; d <= PF; d++) gload(breg[d], d);
+
+    // ---- stage the haloed input tile, f32 -> bf16 (zero outside the image / batch) ----
+    {
+        constexpr int SEG = CIN / 4;
+        constexpr int TOT = NIMG * THH * TWH * SEG;
+        constexpr int IT = (TOT + NT - 1) / NT;
+        constexpr int UB = IT <= 26 ? IT : (IT + 1) / 2 <= 26 ? (IT + 1) / 2 : 16;   // all of a thread's loads in flight at once when they fit
+#pragma unroll
+        for (int it0 = 0; it0 < IT; it0 += UB) {
+            float4 v[UB];
+            int dst[UB];
+#pragma unroll
+            for (int u = 0; u < UB; u++) {
+                const int i = tid + (it0 + u) * NT;
+                int seg = i % SEG;
+                int px = i / SEG;
+                int hx = px % TWH; px /= TWH;
+                int hy = px % THH;
+                int im = px / THH;
+                int gy = y0 + hy - 2, gx = x0 + hx - 2, gb = b0 + im;
+                v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+                dst[u] = (it0 + u < IT && i < TOT) ? im * IMGB + hy * RSB + hx * PSB + seg * 8 : -1;
+                if (dst[u] >= 0 && gb < p.B && (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W)
+                    v[u] = *reinterpret_cast<const float4*>(p.in + (((size_t)gb * p.H + gy) * p.W + gx) * CIN + seg * 4);
+            }
+#pragma unroll
+            for (int u = 0; u < UB; u++) {
+                if (dst[u] >= 0) {
+                    bf16x4 h;
+                    h[0] = (__bf16)v[u].x; h[1] = (__bf16)v[u].y; h[2] = (__bf16)v[u].z; h[3] = (__bf16)v[u].w;
+                    *reinterpret_cast<bf16x4*>(asm_ + dst[u]) = h;
+                }
+            }
+        }
+    }
+
+    // ---- per-lane A byte offsets: which pixel of the tile row `lp` of each of my m-tiles is ----
+    int a_off[TM];
+#pragma unroll
+    for (int i = 0; i < TM; i++) {
+        const int mt = wm * TM + i;
+        int im, y, x;
+        if (POOL) {
+            constexpr int WPR = TW / 2, WPI = (TH / 2) * WPR;
+            int w = mt * 8 + (lp >> 2), q = lp & 3;
+            im = w / WPI;
+            int r = w % WPI;
+            y = 2 * (r / WPR) + (q >> 1);
+            x = 2 * (r % WPR) + (q & 1);
+        } else {
+            int l = mt * 32 + lp;
+            im = l / (TH * TW);
+            int r = l % (TH * TW);
+            y = r / TW;
+            x = r % TW;
+        }
+        a_off[i] = im * IMGB + y * RSB + x * PSB + lh * 16;
+    }
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; i++)
+#pragma unroll
+        for (int j = 0; j < TN; j++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
+
+    const int b_lane = (wn * TN) * 1024 + lane * 16;
+    auto compute = [&](int s) {
+        const unsigned char* bb = bsm + (s & 1) * STAGE_B + b_lane;
+#pragma unroll
+        for (int kbl = 0; kbl < KBS; kbl++) {
+            int tap, c;
+            if (KBS % KB_TAP == 0) { tap = s * (KBS / KB_TAP) + kbl / KB_TAP; c = kbl % KB_TAP; }
+            else { tap = s / (KB_TAP / KBS); c = (s % (KB_TAP / KBS)) * KBS + kbl; }
+            const int ky = tap / 5, kx = tap - 5 * ky;
+            const unsigned char* at = asm_ + ky * RSB + kx * PSB + c * 32;
+            bf16x8 av[TM], bv[TN];
+#pragma unroll
+            for (int i = 0; i < TM; i++) av[i] = *reinterpret_cast<const bf16x8*>(at + a_off[i]);
+#pragma unroll
+            for (int j = 0; j < TN; j++) bv[j] = *reinterpret_cast<const bf16x8*>(bb + (kbl * NTILE + j) * 1024);
+#pragma unroll
+            for (int i = 0; i < TM; i++)
+#pragma unroll
+                for (int j = 0; j < TN; j++)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[i], bv[j], acc[i][j], 0, 0, 0);
+        }
+    };
+
+    lstore(breg[0], 0);
+    gload(breg[0], PF + 1);
+    __syncthreads();                                     // tile + weight stage 0 staged
+    // iteration s: MFMAs of stage s from LDS buffer s&1; stage s+1 leaves its registers for the other buffer (last read
+    // in iteration s-1, before the previous barrier) and those registers take the loads of stage s+PF+2
+    // (a compile-time loop: with run-time slot indices the register ring ends up in scratch memory)
+    bf_static_for<NS>([&](auto sc) {
+        constexpr int s = decltype(sc)::value;
+        constexpr int slot = (s + 1) % (PF + 1);
+        compute(s);
+        lstore(breg[slot], (s + 1) & 1);
+        gload(breg[slot], s + PF + 2);
+        __syncthreads();
+    });
+
+    // ---- epilogue (conv_halo.h) ----
+#pragma unroll
+    for (int j = 0; j < TN; j++) {
+        const int co = (wn * TN + j) * 32 + lp;
+        const float bias = p.bias[co];
+#pragma unroll
+        for (int i = 0; i < TM; i++) {
+            const int mt = wm * TM + i;
+            if (POOL) {
+                constexpr int WPR = TW / 2, WPI = (TH / 2) * WPR;
+                const int Hp = p.H >> 1, Wp = p.W >> 1;
+#pragma unroll
+                for (int g = 0; g < 4; g++) {
+                    float v0 = acc[i][j][4 * g + 0] + bias, v1 = acc[i][j][4 * g + 1] + bias;
+                    float v2 = acc[i][j][4 * g + 2] + bias, v3 = acc[i][j][4 * g + 3] + bias;
+                    if (p.relu) {
+                        v0 = v0 > 0.f ? v0 : 0.f; v1 = v1 > 0.f ? v1 : 0.f;
+                        v2 = v2 > 0.f ? v2 : 0.f; v3 = v3 > 0.f ? v3 : 0.f;
+                    }
+                    float mx = v0 > v1 ? v0 : v1;
+                    mx = mx > v2 ? mx : v2;
+                    mx = mx > v3 ? mx : v3;
+                    int w = mt * 8 + 2 * g + lh;
+                    int im = w / WPI, r = w % WPI;
+                    int py = (y0 >> 1) + r / WPR, px = (x0 >> 1) + r % WPR;
+                    int gb = b0 + im;
+                    if (gb < p.B) p.out[(((size_t)gb * Hp + py) * Wp + px) * COUT + co] = mx;
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; r++) {
+                    int l = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                    int im = l / (TH * TW), q = l % (TH * TW);
+                    int gy = y0 + q / TW, gx = x0 + q % TW, gb = b0 + im;
+                    if (gb < p.B) {
+                        float v = acc[i][j][r] + bias;
+                        if (p.relu) v = v > 0.f ? v : 0.f;
+                        p.out[(((size_t)gb * p.H + gy) * p.W + gx) * COUT + co] = v;
+                    }
+                }
+            }
+        }
+    }
+}
+
+template <int CIN, int COUT, int TH, int TW, int NIMG, int WM, int WN, int TM, int TN, int KBS, bool POOL, int PF = 3>
+static inline hipError_t launch_conv_halo_bf16(const HaloBfParams& p, hipStream_t st) {
+    using G = HaloBfGeom<CIN, COUT, TH, TW, NIMG, KBS, POOL>;
+    constexpr size_t smem = G::LDS_BYTES;
+    static_assert(smem <= 160 * 1024, "LDS");
+    if (p.H % TH || p.W % TW) return hipErrorInvalidValue;
+    auto kern = k_conv_halo_bf16<CIN, COUT, TH, TW, NIMG, WM, WN, TM, TN, KBS, POOL, PF>;
+    static bool attr_set[64] = {false};                  // the attribute is per device
+    int dev_ = 0;
+    if (hipGetDevice(&dev_) != hipSuccess || dev_ < 0 || dev_ >= 64) return hipErrorInvalidDevice;
+    if (!attr_set[dev_]) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           (int)smem);
+        if (e != hipSuccess) return e;
+        attr_set[dev_] = true;
+    }
+    int groups = (p.B + NIMG - 1) / NIMG;
+    groups = (groups + 7) / 8 * 8;
+    dim3 grid((unsigned)(groups * (p.H / TH) * (p.W / TW)));
+    hipLaunchKernelGGL(kern, grid, dim3(WM * WN * 64), smem, st, p);
+    return hipGetLastError();
+}

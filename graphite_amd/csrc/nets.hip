@@ -7,6 +7,7 @@
 #include "conv_igemm.h"
 #include "conv_halo.h"
 #include "conv_halo_cc.h"
+#include "conv_halo_bf16.h"
 #include <stdlib.h>
 #include <math.h>
 #include <stdarg.h>
@@ -21,6 +22,7 @@ struct Layer {
     int Cin = 0, Cout = 0, NP = 0, KH = 1, KW = 1, stride = 1, pad = 0;
     int CinT = 0;            // true (unpadded) input channels, for the algorithmic flop count
     int kchunk = 0;          // 32: k = (ci/32, ky, kx, ci%32) (stride-1 3x3 convs with Cin % 32 == 0), else k = (ky,kx,ci)
+    uint16_t* wbf = nullptr; // bf16 copy for conv_halo_bf16.h: [K/16][Cout/32][2][32][8], k = (ky,kx,ci)  (GR_PREC_BF16 only)
 };
 struct BnDev { float* scale = nullptr; float* shift = nullptr; };
 struct WrnBlock {
@@ -32,6 +34,7 @@ struct WrnBlock {
 struct gr_model {
     gr_ctx* ctx = nullptr;
     int kind = 0;            // 1 = GTSRBNet, 2 = WideResNet
+    int precision = GR_PREC_F32;
     int ncls = 0;
     std::vector<void*> allocs;
     // GTSRBNet
@@ -90,6 +93,31 @@ static int make_layer(gr_model* m, Layer* L, const float* w, const float* bias, 
     return GR_OK;
 }
 
+// float -> bfloat16, round to nearest even (what v_cvt_pk_bf16_f32 does; no NaNs in weights)
+static uint16_t bf16_rne(float f) {
+    uint32_t u;
+    memcpy(&u, &f, 4);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+}
+
+// bf16 operand image of a 5x5 conv for conv_halo_bf16.h (OIHW f32 in): the 16 bytes a lane (cout lp, k half lh) feeds
+// one v_mfma_f32_32x32x16_bf16 are contiguous, lanes and n tiles follow each other, k = (ky*5+kx)*Ci + ci.
+static int make_layer_bf16(gr_model* m, Layer* L, const float* w, int Co, int Ci) {
+    if (Ci % 16 || Co % 32) return gr_fail(m->ctx, GR_EINVAL, "bf16 conv: Cin %% 16 / Cout %% 32");
+    const int K = 25 * Ci, NT32 = Co / 32;
+    std::vector<uint16_t> p((size_t)K * Co);
+    for (int k = 0; k < K; k++) {
+        const int tap = k / Ci, ci = k % Ci, kb = k / 16, lh = (k % 16) / 8, e = k % 8;
+        for (int o = 0; o < Co; o++)
+            p[((((size_t)kb * NT32 + o / 32) * 2 + lh) * 32 + o % 32) * 8 + e] = bf16_rne(w[((size_t)o * Ci + ci) * 25 + tap]);
+    }
+    GR_HIP(m->ctx, hipMalloc((void**)&L->wbf, p.size() * sizeof(uint16_t)));
+    m->allocs.push_back(L->wbf);
+    GR_HIP(m->ctx, hipMemcpy(L->wbf, p.data(), p.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+    return GR_OK;
+}
+
 // eval BatchNorm folded as PyTorch's CPU kernel does: alpha = w/sqrt(var+eps), beta = b - mean*alpha
 static int make_bn(gr_model* m, BnDev* bn, const float* w, const float* b, const float* mean, const float* var, int C) {
     int NP = (C + n_tile(C) - 1) / n_tile(C) * n_tile(C);
@@ -134,6 +162,7 @@ extern "C" int gr_model_load_gtsrb(gr_ctx* ctx, const float* const* t, const int
         rc = upload(m, c, &m->c11);
     }
     for (int l = 1; l <= 6 && !rc; l++) rc = make_layer(m, &m->g[l - 1], t[2 * l], t[2 * l + 1], co[l], ci[l], 5, 5, 1, 2);
+    for (int l = 2; l <= 6 && !rc; l++) rc = make_layer_bf16(m, &m->g[l - 1], t[2 * l], co[l], ci[l]);   // conv2_2 .. conv4_2
     if (!rc) {
         // fc5_1: the reference flattens NCHW (k = c*16 + y*4 + x, GTSRBNet.py:47); activations here are
         // NHWC, so the columns are permuted to k' = (y*4+x)*128 + c.
@@ -241,6 +270,16 @@ extern "C" void gr_model_destroy(gr_model* m) {
     delete m;
 }
 extern "C" int gr_model_num_classes(const gr_model* m) { return m ? m->ncls : GR_EINVAL; }
+
+extern "C" int gr_model_set_precision(gr_model* m, int precision) {
+    if (!m) return GR_EINVAL;
+    if (precision != GR_PREC_F32 && precision != GR_PREC_BF16) return gr_fail(m->ctx, GR_EINVAL, "gr_model_set_precision: %d", precision);
+    if (precision == GR_PREC_BF16 && m->kind != 1)
+        return gr_fail(m->ctx, GR_EINVAL, "gr_model_set_precision: the bf16 kernels cover GTSRBNet only");
+    m->precision = precision;
+    return GR_OK;
+}
+extern "C" int gr_model_get_precision(const gr_model* m) { return m ? m->precision : GR_EINVAL; }
 
 // ---------------------------------------------------------------------------------------------
 // small kernels
@@ -422,18 +461,25 @@ static size_t per_image_floats(const gr_model* m) {
 size_t net_workspace_bytes(const gr_model* m, int N) { return gr_align(per_image_floats(m) * sizeof(float) * (size_t)N); }
 
 // GRAPHITE_HALO_VARIANT="l:v,l:v" picks a tiling variant per layer (tuning runs); default 0.
+// GRAPHITE_BF16_VARIANT: the same for the bf16 kernels.
+static void parse_variants(const char* name, int (&tab)[8]) {
+    for (int i = 0; i < 8; i++) tab[i] = 0;
+    const char* e = getenv(name);
+    while (e && *e) {
+        int l = -1, v = 0;
+        if (sscanf(e, "%d:%d", &l, &v) == 2 && l >= 0 && l < 8 && v >= 0 && v < 8) tab[l] = v;
+        e = strchr(e, ',');
+        if (e) e++;
+    }
+}
 static int halo_variant(int layer) {
     static int tab[8] = {-1, 0, 0, 0, 0, 0, 0, 0};
-    if (tab[0] < 0) {
-        for (int i = 0; i < 8; i++) tab[i] = 0;
-        const char* e = getenv("GRAPHITE_HALO_VARIANT");
-        while (e && *e) {
-            int l = -1, v = 0;
-            if (sscanf(e, "%d:%d", &l, &v) == 2 && l >= 0 && l < 8 && v >= 0 && v < 8) tab[l] = v;
-            e = strchr(e, ',');
-            if (e) e++;
-        }
-    }
+    if (tab[0] < 0) parse_variants("GRAPHITE_HALO_VARIANT", tab);
+    return tab[layer];
+}
+static int bf16_variant(int layer) {
+    static int tab[8] = {-1, 0, 0, 0, 0, 0, 0, 0};
+    if (tab[0] < 0) parse_variants("GRAPHITE_BF16_VARIANT", tab);
     return tab[layer];
 }
 
@@ -489,6 +535,51 @@ static int run_gtsrb_halo(gr_ctx* ctx, const Layer& L, int layer, const float* i
     return GR_OK;
 }
 
+// GTSRBNet's conv2_2 .. conv4_2 on the bf16 matrix cores (conv_halo_bf16.h), f32 activations in and out.
+static int run_gtsrb_halo_bf16(gr_ctx* ctx, const Layer& L, int layer, const float* in, int B, int H, float* out, hipStream_t st) {
+    HaloBfParams p;
+    p.in = in; p.wgt = L.wbf; p.bias = L.bias; p.out = out; p.B = B; p.H = H; p.W = H; p.relu = 1;
+    const bool pool = layer == 1 || layer == 3 || layer == 5;
+    const double M = (double)B * H * H;
+    const double flops = 2.0 * M * L.Cout * 25 * L.CinT;
+    const double bytes = 4.0 * (M * L.CinT + (pool ? M / 4 : M) * L.Cout) + 2.0 * 25.0 * L.CinT * L.Cout;
+    char pname[64];
+    snprintf(pname, sizeof(pname), "k_conv_halo_bf16<conv%d_%d>", 2 + layer / 2, 1 + layer % 2);
+    ProfScope ps_(ctx, pname, st, flops, bytes);
+    hipError_t e = hipErrorInvalidValue;
+    const int v = bf16_variant(layer);
+    //                                 CIN COUT  TH  TW NIMG WM WN TM TN KBS POOL
+#define HB(...) e = launch_conv_halo_bf16<__VA_ARGS__>(p, st)
+    switch (layer * 8 + v) {
+    case 1 * 8 + 0: HB( 32,  32, 16, 32, 1,  4, 1, 4, 1, 10, true ); break;    // conv2_2   (variant 0 = fastest measured)
+    case 1 * 8 + 1: HB( 32,  32,  8, 32, 1,  4, 1, 2, 1, 10, true ); break;
+    case 2 * 8 + 0: HB( 32,  64, 16, 16, 1,  2, 2, 4, 1, 10, false); break;    // conv3_1
+    case 2 * 8 + 1: HB( 32,  64, 16, 16, 1,  4, 1, 2, 2, 10, false); break;
+    case 3 * 8 + 0: HB( 64,  64, 16, 16, 1,  2, 2, 4, 1,  4, true ); break;    // conv3_2
+    case 3 * 8 + 1: HB( 64,  64, 16, 16, 1,  4, 1, 2, 2,  4, true ); break;
+    case 4 * 8 + 0: HB( 64, 128,  8,  8, 4,  4, 2, 2, 2,  4, false); break;    // conv4_1
+    case 4 * 8 + 1: HB( 64, 128,  8,  8, 2,  2, 2, 2, 2,  4, false); break;
+    case 5 * 8 + 0: HB(128, 128,  8,  8, 2,  2, 4, 2, 1,  4, true ); break;    // conv4_2
+    case 5 * 8 + 1: HB(128, 128,  8,  8, 1,  1, 4, 2, 1,  4, true ); break;
+    case 5 * 8 + 2: HB(128, 128,  8,  8, 2,  2, 2, 2, 2,  4, true ); break;
+    // prefetch-depth variants of variant 0 (PF = 1 / 5; default 3)
+    case 1 * 8 + 3: HB( 32,  32, 16, 32, 1,  4, 1, 4, 1, 10, true , 1); break;
+    case 1 * 8 + 4: HB( 32,  32, 16, 32, 1,  4, 1, 4, 1, 10, true , 5); break;
+    case 2 * 8 + 3: HB( 32,  64, 16, 16, 1,  2, 2, 4, 1, 10, false, 1); break;
+    case 2 * 8 + 4: HB( 32,  64, 16, 16, 1,  2, 2, 4, 1, 10, false, 5); break;
+    case 3 * 8 + 3: HB( 64,  64, 16, 16, 1,  2, 2, 4, 1,  4, true , 1); break;
+    case 3 * 8 + 4: HB( 64,  64, 16, 16, 1,  2, 2, 4, 1,  4, true , 5); break;
+    case 4 * 8 + 3: HB( 64, 128,  8,  8, 4,  4, 2, 2, 2,  4, false, 1); break;
+    case 4 * 8 + 4: HB( 64, 128,  8,  8, 4,  4, 2, 2, 2,  4, false, 5); break;
+    case 5 * 8 + 3: HB(128, 128,  8,  8, 2,  2, 4, 2, 1,  4, true , 1); break;
+    case 5 * 8 + 4: HB(128, 128,  8,  8, 2,  2, 4, 2, 1,  4, true , 5); break;
+    default: return gr_fail(ctx, GR_EINVAL, "conv_halo_bf16: no variant %d for layer %d", v, layer);
+    }
+#undef HB
+    if (e != hipSuccess) return gr_fail(ctx, GR_EHIP, "conv_halo_bf16 launch (layer %d): %s", layer, hipGetErrorString(e));
+    return GR_OK;
+}
+
 static bool use_igemm_convs() {      // GRAPHITE_CONV=igemm selects the im2col-chunk kernels for A/B runs
     static int v = -1;
     if (v < 0) { const char* e = getenv("GRAPHITE_CONV"); v = (e && strcmp(e, "igemm") == 0) ? 1 : 0; }
@@ -505,6 +596,23 @@ static int gtsrb_forward(gr_ctx* ctx, gr_model* m, const float* x, int N, float*
     }
     GR_HIP(ctx, hipGetLastError());
     int rc;
+    if (m->precision == GR_PREC_BF16) {
+        // GRAPHITE_BF16_LAYERS = bit mask of the layers (1 = conv2_2 .. 5 = conv4_2) that run in bf16; default all five
+        static int mask = -1;
+        if (mask < 0) { const char* e = getenv("GRAPHITE_BF16_LAYERS"); mask = e ? (int)strtol(e, nullptr, 0) & 0x3e : 0x3e; }
+        auto conv = [&](int l, const float* in, int H, float* out) {
+            return (mask >> l) & 1 ? run_gtsrb_halo_bf16(ctx, m->g[l], l, in, N, H, out, st) : run_gtsrb_halo(ctx, m->g[l], l, in, N, H, out, st);
+        };
+        if ((rc = run_gtsrb_halo(ctx, m->g[0], 0, x4, N, 32, A, st))) return rc;                  // conv2_1 (K = 75) stays fp32
+        if ((rc = conv(1, A, 32, Bf))) return rc;
+        if ((rc = conv(2, Bf, 16, A))) return rc;
+        if ((rc = conv(3, A, 16, Bf))) return rc;
+        if ((rc = conv(4, Bf, 8, A))) return rc;
+        if ((rc = conv(5, A, 8, Bf))) return rc;
+        if ((rc = run_conv(ctx, m->g[6], Bf, N, 1, 1, nullptr, nullptr, A, nullptr, true, false, st))) return rc;     // fc5
+        if ((rc = run_conv(ctx, m->g[7], A, N, 1, 1, nullptr, nullptr, Bf, nullptr, true, false, st))) return rc;     // fc6
+        return run_conv(ctx, m->g[8], Bf, N, 1, 1, nullptr, nullptr, logits, nullptr, false, false, st);             // fc7
+    }
     if (!use_igemm_convs()) {
         if ((rc = run_gtsrb_halo(ctx, m->g[0], 0, x4, N, 32, A, st))) return rc;
         if ((rc = run_gtsrb_halo(ctx, m->g[1], 1, A, N, 32, Bf, st))) return rc;

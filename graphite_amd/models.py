@@ -47,6 +47,11 @@ class _HipClassifier:
     def hip_model(self):
         return self._require()
 
+    def set_precision(self, precision):
+        """'f32' (default, the bit-exact parity path) or 'bf16' (throughput mode, GTSRBNet only): see gr_model_set_precision."""
+        self._require().set_precision(precision)
+        return self
+
 
 class GTSRBNet(_HipClassifier):
     num_classes = 43

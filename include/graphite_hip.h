@@ -117,6 +117,15 @@ int gr_model_load_wrn(gr_ctx* ctx, const float* const* tensors, const int64_t* n
                       int num_classes, gr_model** out);
 void gr_model_destroy(gr_model* m);
 int gr_model_num_classes(const gr_model* m);
+/* Arithmetic of the conv layers.  GR_PREC_F32 (default): fp32 MFMA, the parity path (labels, counts and logits
+ * bit-exact against the oracle).  GR_PREC_BF16: the north star's throughput mode for GTSRBNet -- conv2_2 .. conv4_2
+ * (95 % of the flops) take bf16 operands (activations and weights rounded to nearest even) with f32 accumulation;
+ * everything else stays fp32.  Not bit-exact: logits follow torch's bf16-operand forward (GTSRBNet.py:35-52 with
+ * .bfloat16() operands) to 1e-2 of the largest logit (measured 2e-3..5e-3, the accumulation-order floor), see tests/test_gpu_bf16.py.  WideResNet: GR_EINVAL. */
+#define GR_PREC_F32 0
+#define GR_PREC_BF16 1
+int gr_model_set_precision(gr_model* m, int precision);
+int gr_model_get_precision(const gr_model* m);
 /* forward: x = [N,3,32,32] dev (already in the net's input range) -> logits [N,ncls] dev. */
 int gr_model_forward(gr_ctx* ctx, gr_model* m, const float* x, int N, float* logits, void* stream);
 /* predict(): torch.max(logits,1) first-maximum rule (GTSRBNet.py:66) -> preds [N] int64 dev. */
