@@ -46,6 +46,7 @@ SIGNATURES = {
     "gr_model_num_classes": (_i, [_vp]),
     "gr_model_set_precision": (_i, [_vp, _i]),
     "gr_model_get_precision": (_i, [_vp]),
+    "gr_model_set_bf16_layers": (_i, [_vp, C.c_uint]),
     "gr_model_forward": (_i, [_vp, _vp, _vp, _i, _vp, _vp]),
     "gr_model_predict": (_i, [_vp, _vp, _vp, _i, _vp, _vp]),
     "gr_model_input_grad": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp, _vp]),
@@ -293,6 +294,10 @@ class Model:
         if precision not in self.PRECISIONS:
             raise ValueError(f"precision must be one of {sorted(self.PRECISIONS)}")
         _check(self._ctx, load_library().gr_model_set_precision(self._h, self.PRECISIONS[precision]), "gr_model_set_precision")
+
+    def set_bf16_layers(self, mask):
+        """bit 1 = conv2_2 .. 5 = conv4_2, 6 = fc5 + fc6: the layers that 'bf16' precision runs in bf16 (default 0x7e)."""
+        _check(self._ctx, load_library().gr_model_set_bf16_layers(self._h, int(mask)), "gr_model_set_bf16_layers")
 
     @property
     def precision(self):

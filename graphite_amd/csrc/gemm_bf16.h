@@ -1,0 +1,164 @@
+// gemm_bf16.h -- C[M][N] = act(A[M][K] * W + bias) on v_mfma_f32_32x32x16_bf16, for GTSRBNet's fc5 / fc6 in the bf16
+// throughput mode (GR_PREC_BF16; not the parity path).
+//   A: f32 row-major activations, rounded to bf16 (nearest even) while a BM x BK stage goes global -> registers -> LDS
+//      (row stride BK*2+16 bytes = an odd number of 16-byte slots: conflict-free ds_read_b128 fragments).
+//   W: bf16, packed at load in fragment order [K/16][N/32][2][32][8] (conv_halo_bf16.h), staged the same way.
+//   Two LDS buffers, one barrier per K step of BK, register ring one stage deep beyond the LDS buffers; bias + ReLU
+//   epilogue, f32 store.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "conv_halo_bf16.h"
+
+struct GemmBfParams {
+    const float* a;         // [M][K]
+    const uint16_t* w;      // packed bf16
+    const float* bias;      // [N]
+    float* c;               // [M][N]
+    int M, N, K, relu;
+};
+
+template <int WM, int WN, int TM, int TN, int BK>
+__global__ __launch_bounds__(WM* WN * 64) void k_gemm_bf16(GemmBfParams p) {
+    constexpr int NT = WM * WN * 64;
+    constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
+    constexpr int ASTR = BK * 2 + 16;                     // bytes per A row in LDS
+    constexpr int A_ST = BM * ASTR;
+    constexpr int KBS = BK / 16;
+    constexpr int B_ST = KBS * (BN / 32) * 1024;
+    constexpr int AV = BM * (BK / 4) / NT;                // float4 loads per thread and stage
+    constexpr int BV = B_ST / 16 / NT;                    // 16-byte loads per thread and stage
+    static_assert(BM * (BK / 4) % NT == 0 && (B_ST / 16) % NT == 0, "stage loads must divide evenly");
+    static_assert((ASTR / 16) % 2 == 1, "A row stride must be an odd number of 16-byte slots");
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_g[];
+    unsigned char* asm_ = smem_g;                         // 2 x A_ST
+    unsigned char* bsm = smem_g + 2 * A_ST;               // 2 x B_ST
+
+    const int tid = threadIdx.x;
+    const int wave = tid >> 6, lane = tid & 63;
+    const int wm = wave / WN, wn = wave % WN;
+    const int lp = lane & 31, lh = lane >> 5;
+    const int nbn = p.N / BN;
+    const int m0 = (blockIdx.x / nbn) * BM, n0 = (blockIdx.x % nbn) * BN;   // consecutive workgroups share the A rows
+    const int NS = p.K / BK;
+
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    f32x4 areg[2][AV];
+    u32x4 breg[2][BV];
+    const u32x4* wg = reinterpret_cast<const u32x4*>(p.w);
+    auto gload = [&](f32x4 (&ar)[AV], u32x4 (&br)[BV], int s) {
+        if (s >= NS) s = NS - 1;                          // clamped, never conditional (conv_halo.h)
+#pragma unroll
+        for (int v = 0; v < AV; v++) {
+            const int f = tid + v * NT;
+            int row = m0 + f / (BK / 4);
+            if (row >= p.M) row = p.M - 1;
+            ar[v] = *reinterpret_cast<const f32x4*>(p.a + (size_t)row * p.K + s * BK + (f % (BK / 4)) * 4);
+        }
+#pragma unroll
+        for (int v = 0; v < BV; v++) {
+            const int idx = tid + v * NT;
+            const int c = idx / (BN / 32 * 64), r = idx % (BN / 32 * 64);
+            br[v] = wg[((size_t)(s * KBS + c) * (p.N / 32) + n0 / 32) * 64 + r];
+        }
+    };
+    auto lstore = [&](const f32x4 (&ar)[AV], const u32x4 (&br)[BV], int buf) {
+#pragma unroll
+        for (int v = 0; v < AV; v++) {
+            const int f = tid + v * NT;
+            bf16x4 h;
+            h[0] = (__bf16)ar[v][0]; h[1] = (__bf16)ar[v][1]; h[2] = (__bf16)ar[v][2]; h[3] = (__bf16)ar[v][3];
+            *reinterpret_cast<bf16x4*>(asm_ + buf * A_ST + (f / (BK / 4)) * ASTR + (f % (BK / 4)) * 8) = h;
+        }
+#pragma unroll
+        for (int v = 0; v < BV; v++) *reinterpret_cast<u32x4*>(bsm + buf * B_ST + (tid + v * NT) * 16) = br[v];
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; i++)
+#pragma unroll
+        for (int j = 0; j < TN; j++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
+
+    const int a_lane = (wm * TM * 32 + lp) * ASTR + lh * 16;
+    const int b_lane = (wn * TN) * 1024 + lane * 16;
+    auto compute = [&](int buf) {
+        const unsigned char* ab = asm_ + buf * A_ST + a_lane;
+        const unsigned char* bb = bsm + buf * B_ST + b_lane;
+#pragma unroll
+        for (int c = 0; c < KBS; c++) {
+            bf16x8 av[TM], bv[TN];
+#pragma unroll
+            for (int i = 0; i < TM; i++) av[i] = *reinterpret_cast<const bf16x8*>(ab + i * 32 * ASTR + c * 32);
+#pragma unroll
+            for (int j = 0; j < TN; j++) bv[j] = *reinterpret_cast<const bf16x8*>(bb + (c * (BN / 32) + j) * 1024);
+#pragma unroll
+            for (int i = 0; i < TM; i++)
+#pragma unroll
+                for (int j = 0; j < TN; j++)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[i], bv[j], acc[i][j], 0, 0, 0);
+        }
+    };
+
+    gload(areg[0], breg[0], 0);
+    gload(areg[1], breg[1], 1);
+    lstore(areg[0], breg[0], 0);
+    gload(areg[0], breg[0], 2);
+    __syncthreads();
+    // iteration s: stage s from LDS buffer s&1; stage s+1 leaves register set (s+1)&1 for the other buffer, and that
+    // set takes the loads of stage s+3.  Two iterations per trip keep the register-set indices compile-time.
+    for (int s = 0; s < NS; s += 2) {
+        compute(0);
+        lstore(areg[1], breg[1], 1);
+        gload(areg[1], breg[1], s + 3);
+        __syncthreads();
+        if (s + 1 < NS) {
+            compute(1);
+            lstore(areg[0], breg[0], 0);
+            gload(areg[0], breg[0], s + 4);
+        }
+        __syncthreads();
+    }
+
+#pragma unroll
+    for (int j = 0; j < TN; j++) {
+        const int n = n0 + (wn * TN + j) * 32 + lp;
+        const float bias = p.bias ? p.bias[n] : 0.f;
+#pragma unroll
+        for (int i = 0; i < TM; i++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int m = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                if (m < p.M) {
+                    float v = acc[i][j][r] + bias;
+                    if (p.relu) v = v > 0.f ? v : 0.f;
+                    p.c[(size_t)m * p.N + n] = v;
+                }
+            }
+    }
+}
+
+template <int WM, int WN, int TM, int TN, int BK>
+static inline hipError_t launch_gemm_bf16(const GemmBfParams& p, hipStream_t st) {
+    constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
+    constexpr size_t smem = 2 * (size_t)BM * (BK * 2 + 16) + 2 * (size_t)(BK / 16) * (BN / 32) * 1024;
+    static_assert(smem <= 160 * 1024, "LDS");
+    if (p.M <= 0 || p.N % BN || p.K % BK || p.K / BK < 2) return hipErrorInvalidValue;
+    auto kern = k_gemm_bf16<WM, WN, TM, TN, BK>;
+    static bool attr_set[64] = {false};                   // the attribute is per device
+    int dev_ = 0;
+    if (hipGetDevice(&dev_) != hipSuccess || dev_ < 0 || dev_ >= 64) return hipErrorInvalidDevice;
+    if (!attr_set[dev_]) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           (int)smem);
+        if (e != hipSuccess) return e;
+        attr_set[dev_] = true;
+    }
+    const long long grid = (long long)((p.M + BM - 1) / BM) * (p.N / BN);
+    if (grid > 0x7fffffff) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(WM * WN * 64), smem, st, p);
+    return hipGetLastError();
+}

@@ -8,6 +8,7 @@
 #include "conv_halo.h"
 #include "conv_halo_cc.h"
 #include "conv_halo_bf16.h"
+#include "gemm_bf16.h"
 #include <stdlib.h>
 #include <math.h>
 #include <stdarg.h>
@@ -35,6 +36,7 @@ struct gr_model {
     gr_ctx* ctx = nullptr;
     int kind = 0;            // 1 = GTSRBNet, 2 = WideResNet
     int precision = GR_PREC_F32;
+    int bf16_mask = 0x7e;    // layers that GR_PREC_BF16 runs in bf16: bit 1 = conv2_2 .. bit 5 = conv4_2, bit 6 = fc5 + fc6
     int ncls = 0;
     std::vector<void*> allocs;
     // GTSRBNet
@@ -118,6 +120,20 @@ static int make_layer_bf16(gr_model* m, Layer* L, const float* w, int Co, int Ci
     return GR_OK;
 }
 
+// the same operand image for a linear layer, w = [N][K] row-major (PyTorch [out, in])
+static int make_fc_bf16(gr_model* m, Layer* L, const float* w, int N, int K) {
+    if (K % 16 || N % 32) return gr_fail(m->ctx, GR_EINVAL, "bf16 linear: K %% 16 / N %% 32");
+    const int NT32 = N / 32;
+    std::vector<uint16_t> p((size_t)K * N);
+    for (int n = 0; n < N; n++)
+        for (int k = 0; k < K; k++)
+            p[((((size_t)(k / 16) * NT32 + n / 32) * 2 + (k % 16) / 8) * 32 + n % 32) * 8 + k % 8] = bf16_rne(w[(size_t)n * K + k]);
+    GR_HIP(m->ctx, hipMalloc((void**)&L->wbf, p.size() * sizeof(uint16_t)));
+    m->allocs.push_back(L->wbf);
+    GR_HIP(m->ctx, hipMemcpy(L->wbf, p.data(), p.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+    return GR_OK;
+}
+
 // eval BatchNorm folded as PyTorch's CPU kernel does: alpha = w/sqrt(var+eps), beta = b - mean*alpha
 static int make_bn(gr_model* m, BnDev* bn, const float* w, const float* b, const float* mean, const float* var, int C) {
     int NP = (C + n_tile(C) - 1) / n_tile(C) * n_tile(C);
@@ -171,8 +187,10 @@ extern "C" int gr_model_load_gtsrb(gr_ctx* ctx, const float* const* t, const int
             for (int c = 0; c < 128; c++)
                 for (int s = 0; s < 16; s++) w5[(size_t)o * 2048 + s * 128 + c] = t[14][(size_t)o * 2048 + c * 16 + s];
         rc = make_layer(m, &m->g[6], w5.data(), t[15], 1024, 2048, 1, 1, 1, 0);
+        if (!rc) rc = make_fc_bf16(m, &m->g[6], w5.data(), 1024, 2048);
     }
     if (!rc) rc = make_layer(m, &m->g[7], t[16], t[17], 1024, 1024, 1, 1, 1, 0);
+    if (!rc) rc = make_fc_bf16(m, &m->g[7], t[16], 1024, 1024);
     if (!rc) rc = make_layer(m, &m->g[8], t[18], t[19], 43, 1024, 1, 1, 1, 0);
     // transposed layers for gr_model_input_grad: dX = conv(dY, W') with W'[ci][co][ky][kx] = W[co][ci][4-ky][4-kx]
     for (int l = 1; l <= 6 && !rc; l++) {
@@ -280,6 +298,12 @@ extern "C" int gr_model_set_precision(gr_model* m, int precision) {
     return GR_OK;
 }
 extern "C" int gr_model_get_precision(const gr_model* m) { return m ? m->precision : GR_EINVAL; }
+extern "C" int gr_model_set_bf16_layers(gr_model* m, unsigned mask) {
+    if (!m) return GR_EINVAL;
+    if (mask & ~0x7eu) return gr_fail(m->ctx, GR_EINVAL, "gr_model_set_bf16_layers: mask 0x%x has bits outside 0x7e", mask);
+    m->bf16_mask = (int)mask;
+    return GR_OK;
+}
 
 // ---------------------------------------------------------------------------------------------
 // small kernels
@@ -580,6 +604,18 @@ static int run_gtsrb_halo_bf16(gr_ctx* ctx, const Layer& L, int layer, const flo
     return GR_OK;
 }
 
+// fc5 / fc6 of the bf16 mode (gemm_bf16.h)
+static int run_fc_bf16(gr_ctx* ctx, const Layer& L, const char* name, const float* in, int M, float* out, hipStream_t st) {
+    GemmBfParams p;
+    p.a = in; p.w = L.wbf; p.bias = L.bias; p.c = out; p.M = M; p.N = L.Cout; p.K = L.CinT; p.relu = 1;
+    char pname[64];
+    snprintf(pname, sizeof(pname), "k_gemm_bf16<%s>", name);
+    ProfScope ps_(ctx, pname, st, 2.0 * M * L.Cout * L.CinT, 4.0 * M * (L.CinT + L.Cout) + 2.0 * L.CinT * L.Cout);
+    hipError_t e = launch_gemm_bf16<2, 2, 2, 2, 64>(p, st);
+    if (e != hipSuccess) return gr_fail(ctx, GR_EHIP, "gemm_bf16 launch (%s): %s", name, hipGetErrorString(e));
+    return GR_OK;
+}
+
 static bool use_igemm_convs() {      // GRAPHITE_CONV=igemm selects the im2col-chunk kernels for A/B runs
     static int v = -1;
     if (v < 0) { const char* e = getenv("GRAPHITE_CONV"); v = (e && strcmp(e, "igemm") == 0) ? 1 : 0; }
@@ -597,9 +633,7 @@ static int gtsrb_forward(gr_ctx* ctx, gr_model* m, const float* x, int N, float*
     GR_HIP(ctx, hipGetLastError());
     int rc;
     if (m->precision == GR_PREC_BF16) {
-        // GRAPHITE_BF16_LAYERS = bit mask of the layers (1 = conv2_2 .. 5 = conv4_2) that run in bf16; default all five
-        static int mask = -1;
-        if (mask < 0) { const char* e = getenv("GRAPHITE_BF16_LAYERS"); mask = e ? (int)strtol(e, nullptr, 0) & 0x3e : 0x3e; }
+        const int mask = m->bf16_mask;
         auto conv = [&](int l, const float* in, int H, float* out) {
             return (mask >> l) & 1 ? run_gtsrb_halo_bf16(ctx, m->g[l], l, in, N, H, out, st) : run_gtsrb_halo(ctx, m->g[l], l, in, N, H, out, st);
         };
@@ -609,8 +643,13 @@ static int gtsrb_forward(gr_ctx* ctx, gr_model* m, const float* x, int N, float*
         if ((rc = conv(3, A, 16, Bf))) return rc;
         if ((rc = conv(4, Bf, 8, A))) return rc;
         if ((rc = conv(5, A, 8, Bf))) return rc;
-        if ((rc = run_conv(ctx, m->g[6], Bf, N, 1, 1, nullptr, nullptr, A, nullptr, true, false, st))) return rc;     // fc5
-        if ((rc = run_conv(ctx, m->g[7], A, N, 1, 1, nullptr, nullptr, Bf, nullptr, true, false, st))) return rc;     // fc6
+        if (mask & 0x40) {                                                                         // bit 6: fc5 / fc6
+            if ((rc = run_fc_bf16(ctx, m->g[6], "fc5", Bf, N, A, st))) return rc;
+            if ((rc = run_fc_bf16(ctx, m->g[7], "fc6", A, N, Bf, st))) return rc;
+        } else {
+            if ((rc = run_conv(ctx, m->g[6], Bf, N, 1, 1, nullptr, nullptr, A, nullptr, true, false, st))) return rc;     // fc5
+            if ((rc = run_conv(ctx, m->g[7], A, N, 1, 1, nullptr, nullptr, Bf, nullptr, true, false, st))) return rc;     // fc6
+        }
         return run_conv(ctx, m->g[8], Bf, N, 1, 1, nullptr, nullptr, logits, nullptr, false, false, st);             // fc7
     }
     if (!use_igemm_convs()) {

@@ -1,15 +1,20 @@
-"""GPU check of the bf16 throughput mode (gr_model_set_precision(GR_PREC_BF16)): GTSRBNet's conv2_2 .. conv4_2 on
-v_mfma_f32_32x32x16_bf16, everything else fp32.  This mode is NOT the parity path (fp32 is, bit-exact, see
-test_gpu_parity.py); its bar is a floating-point tolerance, written here:
+"""GPU check of the bf16 throughput mode (gr_model_set_precision(GR_PREC_BF16)): GTSRBNet's conv2_2 .. conv4_2 and
+fc5 / fc6 on v_mfma_f32_32x32x16_bf16, everything else fp32.  This mode is NOT the parity path (fp32 is, bit-exact, see
+test_gpu_parity.py); its bars are floating-point tolerances, written here.
 
-  * logits within BF16_TOL = 1e-2 of the largest |logit| of the plain-PyTorch restatement with the same operand rounding
-    (oracle/gtsrb_torch_reference.forward_bf16: operands rounded to bfloat16, float64 accumulation).  The kernels add the
-    exact products in float32 in the hardware's order; an activation that lands near a bfloat16 rounding boundary then
-    rounds the other way (one bf16 ulp = 0.4-0.8 % of that activation), and the fitted read-out amplifies it: the SAME
-    restatement with float32 instead of float64 accumulation, on the CPU, differs from itself by 1.6e-3, which is the
-    floor for any implementation; measured for the kernels: 1.7e-3 (1 image) to 4.5e-3 (120 images; the maximum grows with the sample);
-  * against the fp32 path (what the reference computes): logits within BF16_VS_F32 = 3e-2 of the largest |logit| and at
-    least 97 % identical labels on transformed views of a sign -- reported, so that a caller can judge the mode.
+Reference: oracle/gtsrb_torch_reference.forward_bf16 -- plain PyTorch with the same operand rounding (activations and
+weights to bfloat16, nearest even) and float64 accumulation.
+
+  * ONE layer in bf16 at a time (gr_model_set_bf16_layers): everything before the layer is the fp32 path, so kernel and
+    reference round the same activations.  Per image e = max |logit - ref| / max |ref|: median <= LAYER_MEDIAN = 1e-4
+    (measured 2e-6 .. 3e-5; a wrong operand index cannot hide there) and max <= LAYER_MAX = 2e-2 (measured <= 3e-3: the few
+    images in which an activation of a LATER layer's input sits on a bf16 rounding boundary and the 1e-6 accumulation-order
+    difference flips it by one bf16 ulp; two CPU restatements that differ only in float32 vs float64 accumulation show the
+    same 4.7e-3).
+  * Whole mode: such flips happen in every image (57 K rounded activations), so two implementations agree only to about
+    the size of the bf16 error itself: max e <= MODE_MAX = 5e-2 against the bf16 reference (measured 1.8e-2 on noise
+    images, 4.5e-3 on sign views) and against the fp32 path (measured 2.6e-2 / 1.3e-2); >= 97 % identical labels and hit
+    counts within 5 of 100 on transformed views of a sign (measured 99.7 %, identical counts).
 """
 import os
 import sys
@@ -25,8 +30,10 @@ from graphite_amd import _hip, models, synth                                # no
 
 pytestmark = pytest.mark.gpu
 
-BF16_TOL = 1e-2
-BF16_VS_F32 = 3e-2
+LAYER_MEDIAN = 1e-4
+LAYER_MAX = 2e-2
+MODE_MAX = 5e-2
+LAYERS = {1: ("conv2_2",), 2: ("conv3_1",), 3: ("conv3_2",), 4: ("conv4_1",), 5: ("conv4_2",), 6: ("fc5_1", "fc6_1")}
 
 
 def _views(n_masks=3, n_xf=40):
@@ -35,27 +42,53 @@ def _views(n_masks=3, n_xf=40):
     return torch.from_numpy(_hip.warp_batch(case["vic"], masks, thetas, case["tab"], 1.0, True).reshape(-1, 3, 32, 32))
 
 
-@pytest.mark.parametrize("n", [1, 37, 120])
-def test_bf16_logits_match_bf16_operand_reference(n):
-    sd = synth.gtsrb_state_dict(readout="toy3")
+def _per_image_err(got, ref):
+    return ((got - ref).abs().max(dim=1).values / float(ref.abs().max())).sort().values
+
+
+@pytest.fixture(scope="module")
+def net():
+    sd = synth.gtsrb_state_dict()
     model = models.GTSRBNet().load_state_dict(sd)
-    x = _views()[:n]
+    tsd = {k: torch.as_tensor(v) for k, v in sd.items()}
+    g = torch.Generator().manual_seed(5)
+    x = torch.cat([_views()[:60], torch.rand(60, 3, 32, 32, generator=g) - 0.5])     # sign views + noise images
+    return model, tsd, x
+
+
+@pytest.mark.parametrize("bit", sorted(LAYERS))
+def test_bf16_single_layer_matches_bf16_operand_reference(net, bit):
+    model, tsd, x = net
+    model.set_precision("bf16")
+    model.hip_model.set_bf16_layers(1 << bit)
+    try:
+        got = model.forward(x).cpu()
+    finally:
+        model.hip_model.set_bf16_layers(0x7e)
+        model.set_precision("f32")
+    f32 = model.forward(x).cpu()
+    ref = G.forward_bf16(tsd, x, LAYERS[bit])
+    e = _per_image_err(got, ref)
+    print(f"{LAYERS[bit]}: median {float(e[len(e) // 2]):.2e}  max {float(e[-1]):.2e}   (bf16 vs fp32: {float(_per_image_err(got, f32)[-1]):.2e})")
+    assert float(e[len(e) // 2]) <= LAYER_MEDIAN
+    assert float(e[-1]) <= LAYER_MAX
+    assert not torch.equal(got, f32), "the layer must actually run different arithmetic"
+
+
+@pytest.mark.parametrize("n", [1, 37, 120])
+def test_bf16_mode_end_to_end(net, n):
+    model, tsd, x = net
+    x = x[:n]
     f32 = model.forward(x).cpu()
     model.set_precision("bf16")
     assert model.hip_model.precision == "bf16"
     got = model.forward(x).cpu()
     model.set_precision("f32")
-    again = model.forward(x).cpu()
-    assert torch.equal(again, f32), "switching back must restore the bit-exact fp32 path"
-    tsd = {k: torch.as_tensor(v) for k, v in sd.items()}
-    ref = G.forward_bf16(tsd, x)
-    scale = float(ref.abs().max())
-    err = float((got - ref).abs().max()) / scale
-    err32 = float((got - f32).abs().max()) / float(f32.abs().max())
-    print(f"bf16 vs bf16-operand reference: {err:.2e} of max |logit|; vs fp32 path: {err32:.2e}")
-    assert err <= BF16_TOL
-    assert err32 <= BF16_VS_F32
-    assert not torch.equal(got, f32), "the bf16 mode must actually run different arithmetic"
+    assert torch.equal(model.forward(x).cpu(), f32), "switching back must restore the bit-exact fp32 path"
+    e = _per_image_err(got, G.forward_bf16(tsd, x))
+    e32 = _per_image_err(got, f32)
+    print(f"n={n}: vs bf16 reference max {float(e[-1]):.2e}; vs fp32 path max {float(e32[-1]):.2e}")
+    assert float(e[-1]) <= MODE_MAX and float(e32[-1]) <= MODE_MAX
 
 
 def test_bf16_labels_and_hit_counts_close_to_fp32():
@@ -81,4 +114,5 @@ def test_bf16_precision_errors():
         g.set_precision("fp8")
     lib = _hip.load_library()
     assert lib.gr_model_set_precision(g.hip_model._h, 7) == -1          # GR_EINVAL
+    assert lib.gr_model_set_bf16_layers(g.hip_model._h, 0x80) == -1
     assert g.hip_model.precision == "f32"
