@@ -120,28 +120,36 @@ __global__ __launch_bounds__(WM* WN * 64) void k_conv_halo_bf16(HaloBfParams p) 
     for (int d = 0; d <= PF; d++) gload(breg[d], d);
 
     // ---- stage the haloed input tile, f32 -> bf16 (zero outside the image / batch) ----
+    // Thread = (4-channel segment, pixel); the pixel walks the tile in steps of NT/SEG with incremental (x, y, image)
+    // updates: at bf16 MFMA rates the index arithmetic of this loop is a visible share of a workgroup's time.
     {
         constexpr int SEG = CIN / 4;
-        constexpr int TOT = NIMG * THH * TWH * SEG;
-        constexpr int IT = (TOT + NT - 1) / NT;
-        constexpr int UB = IT <= 26 ? IT : (IT + 1) / 2 <= 26 ? (IT + 1) / 2 : 16;   // all of a thread's loads in flight at once when they fit
+        static_assert(NT % SEG == 0, "segments per pixel must divide the workgroup");
+        constexpr int PSTEP = NT / SEG;                   // pixels per pass
+        constexpr int NPX = NIMG * THH * TWH;
+        constexpr int IT = (NPX + PSTEP - 1) / PSTEP;
+        constexpr int UB = IT <= 26 ? IT : (IT + 1) / 2 <= 26 ? (IT + 1) / 2 : 16;   // loads in flight per thread
+        static_assert(PSTEP / TWH + 1 <= THH, "tile too small for the incremental walk");
+        const int seg = tid % SEG;
+        int px = tid / SEG;
+        int hx = px % TWH, hy = (px / TWH) % THH, im = px / (TWH * THH);
+        const float* src = p.in + seg * 4;
 #pragma unroll
         for (int it0 = 0; it0 < IT; it0 += UB) {
             float4 v[UB];
             int dst[UB];
 #pragma unroll
             for (int u = 0; u < UB; u++) {
-                const int i = tid + (it0 + u) * NT;
-                int seg = i % SEG;
-                int px = i / SEG;
-                int hx = px % TWH; px /= TWH;
-                int hy = px % THH;
-                int im = px / THH;
-                int gy = y0 + hy - 2, gx = x0 + hx - 2, gb = b0 + im;
+                const int gy = y0 + hy - 2, gx = x0 + hx - 2, gb = b0 + im;
                 v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-                dst[u] = (it0 + u < IT && i < TOT) ? im * IMGB + hy * RSB + hx * PSB + seg * 8 : -1;
+                dst[u] = (it0 + u < IT && px < NPX) ? im * IMGB + hy * RSB + hx * PSB + seg * 8 : -1;
                 if (dst[u] >= 0 && gb < p.B && (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W)
-                    v[u] = *reinterpret_cast<const float4*>(p.in + (((size_t)gb * p.H + gy) * p.W + gx) * CIN + seg * 4);
+                    v[u] = *reinterpret_cast<const float4*>(src + (((size_t)gb * p.H + gy) * p.W + gx) * CIN);
+                px += PSTEP;
+                hx += PSTEP % TWH;
+                hy += PSTEP / TWH;
+                if (hx >= TWH) { hx -= TWH; hy++; }
+                if (hy >= THH) { hy -= THH; im++; }
             }
 #pragma unroll
             for (int u = 0; u < UB; u++) {

@@ -1,0 +1,244 @@
+// conv_halo_cc_bf16.h -- bf16 MFMA convolution for WideResNet's stride-1 3x3 convs (Cin, Cout multiples of 160 / 32):
+// the bf16 "throughput mode" twin of conv_halo_cc.h (NOT the parity path).
+//
+// As conv_halo_cc.h the contraction is walked in channel chunks of CC = 32, k = (chunk, ky, kx, ci mod 32), because a
+// tile with all Cin channels does not fit LDS; operands are shaped for v_mfma_f32_32x32x16_bf16 as in conv_halo_bf16.h:
+//   * A: per chunk the (TH+2)x(TW+2) x 32-channel slice of the tile, f32 -> bf16 (nearest even) on its way into LDS,
+//     pixel stride 80 bytes (5 16-byte slots), row stride chosen for conflict-free ds_read_b128.  The slice of chunk
+//     c+1 is loaded into registers while chunk c is computed, so a chunk boundary costs one extra barrier, no latency.
+//   * B: bf16 weights in fragment order [k-block][Cout/32][2][32][8]; one stage = one tap (2 k-blocks x 5 n-tiles =
+//     10 KB), two LDS buffers, one barrier per stage, register ring three stages deep (9 taps per chunk keep the ring
+//     slot of a tap compile-time).  Stage indices are clamped, never branched on.
+//   * Epilogue as conv_halo_cc.h: + residual, raw store, relu(v*scale+shift) store (folded BN of the consumer), f32.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "conv_halo_bf16.h"
+
+struct HaloCcBfParams {
+    const float* in;        // [B,H,W,Cin] f32 NHWC
+    const uint16_t* wgt;    // bf16, [K/16][Cout/32][2][32][8], k = (chunk, tap, ci%32)
+    const float* res;       // [B,H,W,Cout] or null
+    const float* scale;     // [Cout] folded BN of the consumer, or null
+    const float* shift;
+    float* out_raw;         // [B,H,W,Cout] or null
+    float* out_act;         // [B,H,W,Cout] or null
+    int B, H, W, Cin, Cout;
+};
+
+template <int TH, int TW, int NIMG>
+struct HaloCcBfGeom {
+    static constexpr int CC = 32;
+    static constexpr int THH = TH + 2, TWH = TW + 2;
+    static constexpr int PSB = CC * 2 + 16;
+    static constexpr int RWANT = TW == 8 ? 8 : 0;
+    static constexpr int RS0 = TWH * PSB;
+    static constexpr int RSB = RS0 + ((RWANT - (RS0 / 16) % 16 + 16) % 16) * 16;
+    static constexpr int IMGB = THH * RSB;
+    static constexpr int A_BYTES = NIMG * IMGB;
+};
+
+// WM wavefronts x TM 32-pixel m-tiles cover the NIMG x TH x TW pixels; every wavefront holds TN n-tiles (N = TN*32).
+template <int TH, int TW, int NIMG, int WM, int TM, int TN, int OCC>
+__global__ __launch_bounds__(WM * 64, OCC) void k_conv_halo_cc_bf16(HaloCcBfParams p) {
+    using G = HaloCcBfGeom<TH, TW, NIMG>;
+    constexpr int CC = 32, NT = WM * 64;
+    constexpr int THH = G::THH, TWH = G::TWH, PSB = G::PSB, RSB = G::RSB, IMGB = G::IMGB;
+    constexpr int KBS = CC / 16;                         // k-blocks per stage (one tap)
+    constexpr int STAGE_B = KBS * TN * 1024;
+    constexpr int SV = STAGE_B / 16, TV = TN * 64;       // vectors per stage / per k-block
+    constexpr int VPT = (SV + NT - 1) / NT;
+    constexpr int MT = NIMG * TH * TW / 32;
+    constexpr int SEG = CC / 4, NPX = NIMG * THH * TWH, PSTEP = NT / SEG;
+    constexpr int AIT = (NPX + PSTEP - 1) / PSTEP;       // float4 loads per thread and chunk slice
+    static_assert(MT == WM * TM, "m tiling");
+    static_assert(PSTEP / TWH + 1 <= THH, "tile too small for the incremental walk");
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_cb[];
+    unsigned char* asm_ = smem_cb;
+    unsigned char* bsm = smem_cb + G::A_BYTES;
+
+    const int tid = threadIdx.x;
+    const int wave = tid >> 6, lane = tid & 63;
+    const int lp = lane & 31, lh = lane >> 5;
+    const int tiles_x = p.W / TW, tiles_y = p.H / TH;
+    int bid, ntile;                                      // XCD-aware order, as conv_halo_cc.h
+    {
+        const int tpi = tiles_x * tiles_y, groups = (p.B + NIMG - 1) / NIMG, nts = p.Cout / (TN * 32);
+        const int xcd = blockIdx.x & 7;
+        int j = blockIdx.x >> 3;
+        ntile = j % nts; j /= nts;
+        const int g = (j / tpi) * 8 + xcd;
+        if (g >= groups) return;
+        bid = g * tpi + j % tpi;
+    }
+    const int tx = bid % tiles_x; bid /= tiles_x;
+    const int ty = bid % tiles_y; bid /= tiles_y;
+    const int b0 = bid * NIMG;
+    const int y0 = ty * TH, x0 = tx * TW;
+    const int n0 = ntile * (TN * 32);
+    const int nchunk = p.Cin / CC;
+    const int NS = nchunk * 9;
+
+    // ---- B ring ----
+    const u32x4* wg = reinterpret_cast<const u32x4*>(p.wgt) + (size_t)(n0 / 32) * 64;
+    const size_t kb_stride = (size_t)(p.Cout / 32) * 64;  // vectors per k-block row of the packed weights
+    u32x4 breg[3][VPT];
+    auto gload = [&](u32x4 (&br)[VPT], int s) {
+        if (s >= NS) s = NS - 1;
+#pragma unroll
+        for (int v = 0; v < VPT; v++) {
+            int idx = tid + v * NT;
+            if (SV % NT != 0 && idx >= SV) idx = SV - 1;
+            br[v] = wg[(size_t)(s * KBS + idx / TV) * kb_stride + idx % TV];
+        }
+    };
+    auto lstore = [&](const u32x4 (&br)[VPT], int buf) {
+#pragma unroll
+        for (int v = 0; v < VPT; v++) {
+            const int idx = tid + v * NT;
+            if (SV % NT == 0 || idx < SV) *reinterpret_cast<u32x4*>(bsm + buf * STAGE_B + idx * 16) = br[v];
+        }
+    };
+
+    // ---- A slice: thread = (4-channel segment, pixel walking the tile in steps of NT/SEG) ----
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    f32x4 areg[AIT];
+    const int seg = tid % SEG, px0 = tid / SEG;
+    auto aload = [&](int ch) {
+        if (ch >= nchunk) ch = nchunk - 1;
+        const float* src = p.in + ch * CC + seg * 4;
+        int px = px0, hx = px0 % TWH, hy = (px0 / TWH) % THH, im = px0 / (TWH * THH);
+#pragma unroll
+        for (int u = 0; u < AIT; u++) {
+            const int gy = y0 + hy - 1, gx = x0 + hx - 1, gb = b0 + im;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (px < NPX && gb < p.B && (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W)
+                v = *reinterpret_cast<const f32x4*>(src + (((size_t)gb * p.H + gy) * p.W + gx) * p.Cin);
+            areg[u] = v;
+            px += PSTEP; hx += PSTEP % TWH; hy += PSTEP / TWH;
+            if (hx >= TWH) { hx -= TWH; hy++; }
+            if (hy >= THH) { hy -= THH; im++; }
+        }
+    };
+    auto astore = [&]() {
+        int px = px0, hx = px0 % TWH, hy = (px0 / TWH) % THH, im = px0 / (TWH * THH);
+#pragma unroll
+        for (int u = 0; u < AIT; u++) {
+            if (px < NPX) {
+                bf16x4 h;
+                h[0] = (__bf16)areg[u][0]; h[1] = (__bf16)areg[u][1]; h[2] = (__bf16)areg[u][2]; h[3] = (__bf16)areg[u][3];
+                *reinterpret_cast<bf16x4*>(asm_ + im * IMGB + hy * RSB + hx * PSB + seg * 8) = h;
+            }
+            px += PSTEP; hx += PSTEP % TWH; hy += PSTEP / TWH;
+            if (hx >= TWH) { hx -= TWH; hy++; }
+            if (hy >= THH) { hy -= THH; im++; }
+        }
+    };
+
+    int a_off[TM];
+#pragma unroll
+    for (int i = 0; i < TM; i++) {
+        const int l = (wave * TM + i) * 32 + lp;
+        const int im = l / (TH * TW), r = l % (TH * TW);
+        a_off[i] = im * IMGB + (r / TW) * RSB + (r % TW) * PSB + lh * 16;
+    }
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; i++)
+#pragma unroll
+        for (int j = 0; j < TN; j++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
+
+    aload(0);
+    gload(breg[0], 0);
+    gload(breg[1], 1);
+    gload(breg[2], 2);
+    astore();
+    aload(1);
+    lstore(breg[0], 0);
+    gload(breg[0], 3);
+    __syncthreads();
+
+    for (int ch = 0; ch < nchunk; ch++) {
+        bf_static_for<9>([&](auto tc) {
+            constexpr int t = decltype(tc)::value;
+            constexpr int slot = (t + 1) % 3;             // ring slot of stage s+1 (9 stages per chunk: s % 3 == t % 3)
+            const int s = ch * 9 + t;
+            const unsigned char* at = asm_ + (t / 3) * RSB + (t % 3) * PSB;
+            const unsigned char* bb = bsm + (s & 1) * STAGE_B + lane * 16;
+#pragma unroll
+            for (int c = 0; c < KBS; c++) {
+                bf16x8 av[TM], bv[TN];
+#pragma unroll
+                for (int i = 0; i < TM; i++) av[i] = *reinterpret_cast<const bf16x8*>(at + a_off[i] + c * 32);
+#pragma unroll
+                for (int j = 0; j < TN; j++) bv[j] = *reinterpret_cast<const bf16x8*>(bb + (c * TN + j) * 1024);
+#pragma unroll
+                for (int i = 0; i < TM; i++)
+#pragma unroll
+                    for (int j = 0; j < TN; j++)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[i], bv[j], acc[i][j], 0, 0, 0);
+            }
+            lstore(breg[slot], (s + 1) & 1);
+            gload(breg[slot], s + 4);
+            __syncthreads();
+        });
+        // every wave is past its last read of this chunk's slice: the next one (already in registers) takes its place
+        astore();
+        aload(ch + 2);
+        __syncthreads();
+    }
+
+    // ---- epilogue (conv_halo_cc.h, scalar columns) ----
+#pragma unroll
+    for (int j = 0; j < TN; j++) {
+        const int co = n0 + j * 32 + lp;
+        const float sc = p.out_act ? p.scale[co] : 0.f;
+        const float sh = p.out_act ? p.shift[co] : 0.f;
+#pragma unroll
+        for (int i = 0; i < TM; i++) {
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int l = (wave * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                const int im = l / (TH * TW), q = l % (TH * TW);
+                const int gy = y0 + q / TW, gx = x0 + q % TW, gb = b0 + im;
+                if (gb >= p.B) continue;
+                const size_t row = (((size_t)gb * p.H + gy) * p.W + gx) * p.Cout;
+                float v = acc[i][j][r];
+                if (p.res) v = v + p.res[row + co];
+                if (p.out_raw) p.out_raw[row + co] = v;
+                if (p.out_act) {
+                    float w = fmaf(v, sc, sh);
+                    p.out_act[row + co] = w > 0.f ? w : 0.f;
+                }
+            }
+        }
+    }
+}
+
+template <int TH, int TW, int NIMG, int WM, int TM, int TN, int OCC>
+static inline hipError_t launch_conv_halo_cc_bf16(const HaloCcBfParams& p, hipStream_t st) {
+    using G = HaloCcBfGeom<TH, TW, NIMG>;
+    constexpr size_t smem = G::A_BYTES + 2 * (size_t)(2 * TN * 1024);
+    static_assert(smem <= 160 * 1024, "LDS");
+    if (p.H % TH || p.W % TW || p.Cin % 32 || p.Cout % (TN * 32) || (p.out_act && !(p.scale && p.shift))) return hipErrorInvalidValue;
+    auto kern = k_conv_halo_cc_bf16<TH, TW, NIMG, WM, TM, TN, OCC>;
+    static bool attr_set[64] = {false};                  // the attribute is per device
+    int dev_ = 0;
+    if (hipGetDevice(&dev_) != hipSuccess || dev_ < 0 || dev_ >= 64) return hipErrorInvalidDevice;
+    if (!attr_set[dev_]) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           (int)smem);
+        if (e != hipSuccess) return e;
+        attr_set[dev_] = true;
+    }
+    long long groups = (p.B + NIMG - 1) / NIMG;
+    groups = (groups + 7) / 8 * 8;
+    const long long nblk = groups * (p.H / TH) * (p.W / TW) * (p.Cout / (TN * 32));
+    if (nblk > 0x7fffffffLL) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(WM * 64), smem, st, p);
+    return hipGetLastError();
+}

@@ -19,7 +19,7 @@ struct GemmBfParams {
 };
 
 template <int WM, int WN, int TM, int TN, int BK>
-__global__ __launch_bounds__(WM* WN * 64) void k_gemm_bf16(GemmBfParams p) {
+__global__ __launch_bounds__(WM* WN * 64, 2) void k_gemm_bf16(GemmBfParams p) {
     constexpr int NT = WM * WN * 64;
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
     constexpr int ASTR = BK * 2 + 16;                     // bytes per A row in LDS

@@ -9,6 +9,7 @@
 #include "conv_halo_cc.h"
 #include "conv_halo_bf16.h"
 #include "gemm_bf16.h"
+#include "conv_halo_cc_bf16.h"
 #include <stdlib.h>
 #include <math.h>
 #include <stdarg.h>
@@ -114,6 +115,23 @@ static int make_layer_bf16(gr_model* m, Layer* L, const float* w, int Co, int Ci
         for (int o = 0; o < Co; o++)
             p[((((size_t)kb * NT32 + o / 32) * 2 + lh) * 32 + o % 32) * 8 + e] = bf16_rne(w[((size_t)o * Ci + ci) * 25 + tap]);
     }
+    GR_HIP(m->ctx, hipMalloc((void**)&L->wbf, p.size() * sizeof(uint16_t)));
+    m->allocs.push_back(L->wbf);
+    GR_HIP(m->ctx, hipMemcpy(L->wbf, p.data(), p.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+    return GR_OK;
+}
+
+// WideResNet's stride-1 3x3 convs for conv_halo_cc_bf16.h: k = ((ci/32)*9 + ky*3+kx)*32 + ci%32 (OIHW f32 in)
+static int make_layer_bf16_cc(gr_model* m, Layer* L, const float* w, int Co, int Ci) {
+    if (Ci % 32 || Co % 32) return gr_fail(m->ctx, GR_EINVAL, "bf16 3x3 conv: Cin %% 32 / Cout %% 32");
+    const int NT32 = Co / 32;
+    std::vector<uint16_t> p((size_t)9 * Ci * Co);
+    for (int ci = 0; ci < Ci; ci++)
+        for (int tap = 0; tap < 9; tap++) {
+            const int k = ((ci / 32) * 9 + tap) * 32 + ci % 32, kb = k / 16, lh = (k % 16) / 8, e = k % 8;
+            for (int o = 0; o < Co; o++)
+                p[((((size_t)kb * NT32 + o / 32) * 2 + lh) * 32 + o % 32) * 8 + e] = bf16_rne(w[((size_t)o * Ci + ci) * 9 + tap]);
+        }
     GR_HIP(m->ctx, hipMalloc((void**)&L->wbf, p.size() * sizeof(uint16_t)));
     m->allocs.push_back(L->wbf);
     GR_HIP(m->ctx, hipMemcpy(L->wbf, p.data(), p.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
@@ -257,12 +275,14 @@ extern "C" int gr_model_load_wrn(gr_ctx* ctx, const float* const* t, const int64
             ti += 4;
             if (!rc) rc = expect(ctx, numel, ti, (int64_t)b.cout * b.cin * 9);
             if (!rc) rc = make_layer(m, &b.conv1, t[ti], nullptr, b.cout, b.cin, 3, 3, b.stride, 1);
+            if (!rc && b.stride == 1 && b.cin % 32 == 0 && b.cout % 160 == 0) rc = make_layer_bf16_cc(m, &b.conv1, t[ti], b.cout, b.cin);
             ti++;
             for (int q = 0; q < 4 && !rc; q++) rc = expect(ctx, numel, ti + q, b.cout);
             if (!rc) rc = make_bn(m, &b.bn2, t[ti], t[ti + 1], t[ti + 2], t[ti + 3], b.cout);
             ti += 4;
             if (!rc) rc = expect(ctx, numel, ti, (int64_t)b.cout * b.cout * 9);
             if (!rc) rc = make_layer(m, &b.conv2, t[ti], nullptr, b.cout, b.cout, 3, 3, 1, 1);
+            if (!rc && b.cout % 160 == 0) rc = make_layer_bf16_cc(m, &b.conv2, t[ti], b.cout, b.cout);
             ti++;
             if (b.has_sc) {
                 if (!rc) rc = expect(ctx, numel, ti, (int64_t)b.cout * b.cin);
@@ -292,8 +312,12 @@ extern "C" int gr_model_num_classes(const gr_model* m) { return m ? m->ncls : GR
 extern "C" int gr_model_set_precision(gr_model* m, int precision) {
     if (!m) return GR_EINVAL;
     if (precision != GR_PREC_F32 && precision != GR_PREC_BF16) return gr_fail(m->ctx, GR_EINVAL, "gr_model_set_precision: %d", precision);
-    if (precision == GR_PREC_BF16 && m->kind != 1)
-        return gr_fail(m->ctx, GR_EINVAL, "gr_model_set_precision: the bf16 kernels cover GTSRBNet only");
+    if (precision == GR_PREC_BF16 && m->kind != 1) {
+        bool any = false;
+        for (const WrnBlock& b : m->blocks) any = any || b.conv1.wbf || b.conv2.wbf;
+        if (!any) return gr_fail(m->ctx, GR_EINVAL, "gr_model_set_precision: this WideResNet has no layer the bf16 kernels cover "
+                                                     "(stride-1 3x3 convs with Cout %% 160 == 0)");
+    }
     m->precision = precision;
     return GR_OK;
 }
@@ -382,9 +406,11 @@ __global__ void k_argmax_hits(const float* __restrict__ logits, int N, int ncls,
 // ---------------------------------------------------------------------------------------------
 static bool use_igemm_convs();
 static int halo_variant(int layer);
+static int bf16_variant(int layer);
 
 static int run_conv(gr_ctx* ctx, const Layer& L, const float* in, int B, int H, int W, const float* res, const BnDev* act,
-                    float* out_raw, float* out_act, bool relu, bool pool, hipStream_t st, const float* gate = nullptr) {
+                    float* out_raw, float* out_act, bool relu, bool pool, hipStream_t st, const float* gate = nullptr,
+                    int precision = GR_PREC_F32) {
     ConvParams p;
     p.in = in; p.wgt = L.w; p.bias = L.bias; p.res = res; p.gate = gate;
     p.scale = act ? act->scale : nullptr; p.shift = act ? act->shift : nullptr;
@@ -412,6 +438,35 @@ static int run_conv(gr_ctx* ctx, const Layer& L, const float* in, int B, int H, 
                                 (double)(pool ? M / 4 : M) * L.Cout * ((out_raw ? 1 : 0) + (out_act ? 1 : 0) + (res ? 1 : 0)));
     char pname[64];
     if (L.kchunk && bk != 32) return gr_fail(ctx, GR_ESTATE, "conv: chunked layer needs BK = 32");
+    if (precision == GR_PREC_BF16 && L.wbf && L.kchunk == 32 && bn == 160 && !pool && !L.bias && !relu && !gate && H == W &&
+        (H == 32 || H == 16 || H == 8)) {
+        HaloCcBfParams q;
+        q.in = in; q.wgt = L.wbf; q.res = res; q.scale = p.scale; q.shift = p.shift; q.out_raw = out_raw; q.out_act = out_act;
+        q.B = B; q.H = H; q.W = W; q.Cin = L.Cin; q.Cout = L.Cout;
+        const int v = bf16_variant(H == 32 ? 0 : H == 16 ? 1 : 2);
+        snprintf(pname, sizeof(pname), "k_conv_halo_cc_bf16<%dx%d,v%d>", H, H, v);
+        ProfScope ps_(ctx, pname, st, flops, bytes);
+        //                                         TH  TW NIMG WM TM TN OCC
+#define HCB(...) e = launch_conv_halo_cc_bf16<__VA_ARGS__>(q, st)
+        if (H >= 16) {
+            switch (v) {
+            case 0: HCB( 8, 16, 1,  4, 1, 5, 2); break;
+            case 1: HCB(16, 16, 1,  4, 2, 5, 2); break;
+            case 2: HCB( 8, 16, 1,  4, 1, 5, 3); break;
+            default: return gr_fail(ctx, GR_EINVAL, "conv_halo_cc_bf16: no variant %d", v);
+            }
+        } else {
+            switch (v) {
+            case 0: HCB( 8,  8, 2,  4, 1, 5, 2); break;
+            case 1: HCB( 8,  8, 4,  4, 2, 5, 2); break;
+            case 2: HCB( 8,  8, 2,  4, 1, 5, 3); break;
+            default: return gr_fail(ctx, GR_EINVAL, "conv_halo_cc_bf16: no variant %d", v);
+            }
+        }
+#undef HCB
+        if (e != hipSuccess) return gr_fail(ctx, GR_EHIP, "conv_halo_cc_bf16 launch (H=%d): %s", H, hipGetErrorString(e));
+        return GR_OK;
+    }
     if (L.kchunk == 32 && bn == 160 && !pool && !use_igemm_convs() && H == W && (H == 32 || H == 16 || H == 8)) {
         HaloCcParams q;
         q.in = in; q.wgt = L.w; q.bias = L.bias; q.res = res; q.scale = p.scale; q.shift = p.shift;
@@ -695,7 +750,7 @@ static int wrn_forward(gr_ctx* ctx, gr_model* m, const float* x, int N, float* l
     for (size_t bi = 0; bi < nb; bi++) {
         WrnBlock& b = m->blocks[bi];
         int Ho = H / b.stride;
-        if ((rc = run_conv(ctx, b.conv1, o, N, H, H, nullptr, &b.bn2, nullptr, u, false, false, st))) return rc;
+        if ((rc = run_conv(ctx, b.conv1, o, N, H, H, nullptr, &b.bn2, nullptr, u, false, false, st, nullptr, m->precision))) return rc;
         const float* res = xr;
         if (b.has_sc) {
             if ((rc = run_conv(ctx, b.sc, o, N, H, H, nullptr, nullptr, s, nullptr, false, false, st))) return rc;
@@ -705,7 +760,7 @@ static int wrn_forward(gr_ctx* ctx, gr_model* m, const float* x, int N, float* l
         const BnDev* nbn = last ? &m->bnf : &m->blocks[bi + 1].bn1;
         bool need_raw = !last && !m->blocks[bi + 1].has_sc;
         // o is free once conv1 and the shortcut have consumed it: the activated output goes there
-        if ((rc = run_conv(ctx, b.conv2, u, N, Ho, Ho, res, nbn, need_raw ? y : nullptr, o, false, false, st))) return rc;
+        if ((rc = run_conv(ctx, b.conv2, u, N, Ho, Ho, res, nbn, need_raw ? y : nullptr, o, false, false, st, nullptr, m->precision))) return rc;
         if (need_raw) { float* tmp = xr; xr = y; y = tmp; }
         H = Ho;
     }

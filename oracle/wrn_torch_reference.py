@@ -1,0 +1,37 @@
+"""TEST INFRASTRUCTURE (oracle): WideResNet.forward (reference cifar/wideresnet.py:25-34, 86-94, eval mode) as plain-PyTorch
+code on a state dict, with the operand rounding of the HIP library's GR_PREC_BF16 mode as an option: the stride-1 3x3
+convs whose Cout is a multiple of 160 take activations and weights rounded to bfloat16 (nearest even) and are summed in
+float64 (order-independent; the matrix cores accumulate in float32); everything else -- first conv, strided convs,
+1x1 shortcuts, BatchNorm, the linear layer -- stays fp32.  A tolerance reference, not a bit-exact one.
+Only tests/ and bench.py's checker legs import it."""
+import torch
+import torch.nn.functional as F
+
+
+def _bn(sd, p, x):
+    return F.batch_norm(x, sd[p + ".running_mean"], sd[p + ".running_var"], sd[p + ".weight"], sd[p + ".bias"], False, 0.0, 1e-5)
+
+
+def _conv(x, w, stride, bf16):
+    pad = w.shape[-1] // 2
+    if bf16 and stride == 1 and w.shape[-1] == 3 and w.shape[0] % 160 == 0 and w.shape[1] % 32 == 0:
+        return F.conv2d(x.bfloat16().double(), w.bfloat16().double(), None, 1, pad).float()
+    return F.conv2d(x, w, None, stride, pad)
+
+
+def forward(sd, x, depth=34, widen=10, bf16=False):
+    n = (depth - 4) // 6
+    ch = [16, 16 * widen, 32 * widen, 64 * widen]
+    out = _conv(x, sd["conv1.weight"], 1, bf16)
+    for bi, stride in ((1, 1), (2, 2), (3, 2)):
+        for i in range(n):
+            p = f"block{bi}.layer.{i}"
+            cin = ch[bi - 1] if i == 0 else ch[bi]
+            s = stride if i == 0 else 1
+            o = F.relu(_bn(sd, p + ".bn1", out))                              # :27 / :29
+            y = F.relu(_bn(sd, p + ".bn2", _conv(o, sd[p + ".conv1.weight"], s, bf16)))   # :30
+            y = _conv(y, sd[p + ".conv2.weight"], 1, bf16)                    # :33
+            out = (out if cin == ch[bi] else _conv(o, sd[p + ".convShortcut.weight"], s, bf16)) + y   # :34
+    out = F.relu(_bn(sd, "bn1", out))
+    out = F.avg_pool2d(out, 8).reshape(-1, ch[3])
+    return F.linear(out, sd["fc.weight"], sd["fc.bias"])

@@ -14,6 +14,8 @@ depth = int(sys.argv[2]) if len(sys.argv) > 2 else 34
 widen = int(sys.argv[3]) if len(sys.argv) > 3 else 10
 m = models.WideResNet(depth=depth, widen_factor=widen)
 m.load_state_dict(synth.wrn_state_dict("wrn-v1", depth, widen, 10, include_unused=True))
+if os.environ.get("GRAPHITE_PREC") == "bf16":      # the throughput mode (stride-1 3x3 convs on bf16 operands)
+    m.set_precision("bf16")
 x = torch.rand(N, 3, 32, 32, device="cuda")
 m.forward(x)
 torch.cuda.synchronize()
