@@ -104,6 +104,24 @@ def extras(_hip, engine, models, synth):
             "conv_tflops": cfl / (cms * 1e-3) / 1e12 if cms else None,
             "conv_frac_of_f32_mfma_peak": cfl / (cms * 1e-3) / 1e12 / PEAK_F32_MFMA if cms else None,
             "hits_checksum": int(h.sum().item())}
+        if name == "sweep_64x100":      # the same sweep in the bf16 throughput mode (stride-1 3x3 convs on bf16 operands)
+            wrn.set_precision("bf16")
+            engine.tr_hits(wrn, img_d, md, td, xf, 3, pt_file=None, model_type='CIFAR')
+            torch.cuda.synchronize()
+            _hip.profile_reset(); _hip.profile_enable(True)
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                h16 = engine.tr_hits(wrn, img_d, md, td, xf, 3, pt_file=None, model_type='CIFAR')
+            torch.cuda.synchronize()
+            dt16 = (time.perf_counter() - t0) / reps
+            _hip.profile_enable(False)
+            p16 = {k: v for k, v in _hip.profile_read().items() if "bf16" in k and v["ms"] > 0}
+            wrn.set_precision("f32")
+            res["config3_cifar_wrn34_10_sweep_64x100_bf16_mode"] = {
+                "images_per_s": C * 100 / dt16, "ms_per_launch": 1e3 * dt16, "speedup_vs_f32": dt / dt16,
+                "bf16_conv_tflops": sum(v["flops"] for v in p16.values()) / (sum(v["ms"] for v in p16.values()) * 1e-3) / 1e12,
+                "bf16_conv_frac_of_bf16_mfma_peak": sum(v["flops"] for v in p16.values()) / (sum(v["ms"] for v in p16.values()) * 1e-3) / 1e12 / PEAK_BF16_MFMA,
+                "max_abs_hit_count_diff_vs_f32_of_100": int((h16 - h).abs().max().item())}
     del wrn
     # ---- config 5: PatchGuard parameter table (pg_transforms.py:67-94, baseline=True); the BagNet robust classifier is
     # un-vendored third-party code with no weights here, so only the warp stage is timed
