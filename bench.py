@@ -392,7 +392,7 @@ def main():
             dh = (h16 - hits).abs()
             out.setdefault("other_configs", {})["config4_bf16_throughput_mode"] = {
                 "images_per_s": C_total * T / bdt, "ms_per_step": 1000.0 * bdt, "dtype": "bf16 operands, f32 accumulation "
-                "(conv2_2..conv4_2, fc5, fc6); conv1_1, conv2_1, fc7 and the warp stay f32",
+                "(conv2_1..conv4_2, fc5, fc6); conv1_1, fc7 and the warp stay f32",
                 "speedup_vs_f32": (C_total * T / bdt) / value,
                 "hit_counts_vs_f32": {"identical_candidates": int((dh == 0).sum().item()), "candidates": int(dh.numel()),
                                       "max_abs_diff_of_%d" % T: int(dh.max().item()),

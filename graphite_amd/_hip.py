@@ -290,13 +290,13 @@ class Model:
     PRECISIONS = {"f32": 0, "bf16": 1}                    # GR_PREC_F32, GR_PREC_BF16
 
     def set_precision(self, precision):
-        """'f32' (default; the parity path) or 'bf16' (GTSRBNet conv2_2..conv4_2 on bf16 operands, f32 accumulation)."""
+        """'f32' (default; the parity path) or 'bf16' (conv / linear layers on bf16 operands, f32 accumulation; see gr_model_set_precision)."""
         if precision not in self.PRECISIONS:
             raise ValueError(f"precision must be one of {sorted(self.PRECISIONS)}")
         _check(self._ctx, load_library().gr_model_set_precision(self._h, self.PRECISIONS[precision]), "gr_model_set_precision")
 
     def set_bf16_layers(self, mask):
-        """bit 1 = conv2_2 .. 5 = conv4_2, 6 = fc5 + fc6: the layers that 'bf16' precision runs in bf16 (default 0x7e)."""
+        """bit 0 = conv2_1 .. 5 = conv4_2, 6 = fc5 + fc6: the layers that 'bf16' precision runs in bf16 (default 0x7f)."""
         _check(self._ctx, load_library().gr_model_set_bf16_layers(self._h, int(mask)), "gr_model_set_bf16_layers")
 
     @property

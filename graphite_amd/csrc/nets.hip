@@ -10,6 +10,7 @@
 #include "conv_halo_bf16.h"
 #include "gemm_bf16.h"
 #include "conv_halo_cc_bf16.h"
+#include "conv21_bf16.h"
 #include <stdlib.h>
 #include <math.h>
 #include <stdarg.h>
@@ -37,7 +38,7 @@ struct gr_model {
     gr_ctx* ctx = nullptr;
     int kind = 0;            // 1 = GTSRBNet, 2 = WideResNet
     int precision = GR_PREC_F32;
-    int bf16_mask = 0x7e;    // layers that GR_PREC_BF16 runs in bf16: bit 1 = conv2_2 .. bit 5 = conv4_2, bit 6 = fc5 + fc6
+    int bf16_mask = 0x7f;    // layers that GR_PREC_BF16 runs in bf16: bit 0 = conv2_1 .. bit 5 = conv4_2, bit 6 = fc5 + fc6
     int ncls = 0;
     std::vector<void*> allocs;
     // GTSRBNet
@@ -121,6 +122,24 @@ static int make_layer_bf16(gr_model* m, Layer* L, const float* w, int Co, int Ci
     return GR_OK;
 }
 
+// conv2_1 for conv21_bf16.h: k-block = (ky, half of the kernel row), k inside = kx*4 + c, zero where kx > 4 or c == 3
+static int make_conv21_bf16(gr_model* m, Layer* L, const float* w /* [32][3][5][5] */) {
+    std::vector<uint16_t> p((size_t)10 * 2 * 32 * 8, 0);
+    for (int ky = 0; ky < 5; ky++)
+        for (int cb = 0; cb < 2; cb++)
+            for (int lh = 0; lh < 2; lh++)
+                for (int e = 0; e < 8; e++) {
+                    const int rowk = cb * 16 + lh * 8 + e, kx = rowk / 4, ch = rowk % 4;
+                    if (kx > 4 || ch > 2) continue;
+                    for (int o = 0; o < 32; o++)
+                        p[((((size_t)(ky * 2 + cb)) * 2 + lh) * 32 + o) * 8 + e] = bf16_rne(w[((size_t)o * 3 + ch) * 25 + ky * 5 + kx]);
+                }
+    GR_HIP(m->ctx, hipMalloc((void**)&L->wbf, p.size() * sizeof(uint16_t)));
+    m->allocs.push_back(L->wbf);
+    GR_HIP(m->ctx, hipMemcpy(L->wbf, p.data(), p.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+    return GR_OK;
+}
+
 // WideResNet's stride-1 3x3 convs for conv_halo_cc_bf16.h: k = ((ci/32)*9 + ky*3+kx)*32 + ci%32 (OIHW f32 in)
 static int make_layer_bf16_cc(gr_model* m, Layer* L, const float* w, int Co, int Ci) {
     if (Ci % 32 || Co % 32) return gr_fail(m->ctx, GR_EINVAL, "bf16 3x3 conv: Cin %% 32 / Cout %% 32");
@@ -196,6 +215,7 @@ extern "C" int gr_model_load_gtsrb(gr_ctx* ctx, const float* const* t, const int
         rc = upload(m, c, &m->c11);
     }
     for (int l = 1; l <= 6 && !rc; l++) rc = make_layer(m, &m->g[l - 1], t[2 * l], t[2 * l + 1], co[l], ci[l], 5, 5, 1, 2);
+    if (!rc) rc = make_conv21_bf16(m, &m->g[0], t[2]);
     for (int l = 2; l <= 6 && !rc; l++) rc = make_layer_bf16(m, &m->g[l - 1], t[2 * l], co[l], ci[l]);   // conv2_2 .. conv4_2
     if (!rc) {
         // fc5_1: the reference flattens NCHW (k = c*16 + y*4 + x, GTSRBNet.py:47); activations here are
@@ -324,7 +344,7 @@ extern "C" int gr_model_set_precision(gr_model* m, int precision) {
 extern "C" int gr_model_get_precision(const gr_model* m) { return m ? m->precision : GR_EINVAL; }
 extern "C" int gr_model_set_bf16_layers(gr_model* m, unsigned mask) {
     if (!m) return GR_EINVAL;
-    if (mask & ~0x7eu) return gr_fail(m->ctx, GR_EINVAL, "gr_model_set_bf16_layers: mask 0x%x has bits outside 0x7e", mask);
+    if (mask & ~0x7fu) return gr_fail(m->ctx, GR_EINVAL, "gr_model_set_bf16_layers: mask 0x%x has bits outside 0x7f", mask);
     m->bf16_mask = (int)mask;
     return GR_OK;
 }
@@ -692,7 +712,13 @@ static int gtsrb_forward(gr_ctx* ctx, gr_model* m, const float* x, int N, float*
         auto conv = [&](int l, const float* in, int H, float* out) {
             return (mask >> l) & 1 ? run_gtsrb_halo_bf16(ctx, m->g[l], l, in, N, H, out, st) : run_gtsrb_halo(ctx, m->g[l], l, in, N, H, out, st);
         };
-        if ((rc = run_gtsrb_halo(ctx, m->g[0], 0, x4, N, 32, A, st))) return rc;                  // conv2_1 (K = 75) stays fp32
+        if (mask & 1) {
+            Conv21BfParams q;
+            q.in = x4; q.wgt = m->g[0].wbf; q.bias = m->g[0].bias; q.out = A; q.B = N;
+            ProfScope ps_(ctx, "k_conv21_bf16<conv2_1>", st, 2.0 * N * 1024 * 32 * 75, 4.0 * N * 1024 * (3 + 32));
+            hipError_t e = launch_conv21_bf16<16>(q, st);
+            if (e != hipSuccess) return gr_fail(ctx, GR_EHIP, "conv21_bf16 launch: %s", hipGetErrorString(e));
+        } else if ((rc = run_gtsrb_halo(ctx, m->g[0], 0, x4, N, 32, A, st))) return rc;
         if ((rc = conv(1, A, 32, Bf))) return rc;
         if ((rc = conv(2, Bf, 16, A))) return rc;
         if ((rc = conv(3, A, 16, Bf))) return rc;

@@ -118,18 +118,20 @@ int gr_model_load_wrn(gr_ctx* ctx, const float* const* tensors, const int64_t* n
 void gr_model_destroy(gr_model* m);
 int gr_model_num_classes(const gr_model* m);
 /* Arithmetic of the conv layers.  GR_PREC_F32 (default): fp32 MFMA, the parity path (labels, counts and logits
- * bit-exact against the oracle).  GR_PREC_BF16: the north star's throughput mode for GTSRBNet -- conv2_2 .. conv4_2
- * and fc5 / fc6 (98 % of the flops) take bf16 operands (activations and weights rounded to nearest even) with f32
- * accumulation; conv1_1, conv2_1, fc7 stay fp32.  Not bit-exact.  Each layer alone follows its restatement (torch,
+ * bit-exact against the oracle).  GR_PREC_BF16: the north star's throughput mode -- GTSRBNet's conv2_1 .. conv4_2
+ * and fc5 / fc6 (all but 0.03 % of the flops) take bf16 operands (activations and weights rounded to nearest even) with f32
+ * accumulation; conv1_1 and fc7 stay fp32.  Not bit-exact.  Each layer alone follows its restatement (torch,
  * .bfloat16() operands, wide accumulation) to a median 1e-5 of the largest logit; end to end, activations that land on a
  * bf16 rounding boundary round differently in any two implementations, so logits agree to ~1e-2 of the largest logit --
- * the same order as bf16 against fp32 itself (tests/test_gpu_bf16.py has the numbers).  WideResNet: GR_EINVAL. */
+ * the same order as bf16 against fp32 itself (tests/test_gpu_bf16.py has the numbers).  WideResNet: the stride-1 3x3
+ * convs with Cout % 160 == 0 (91 % of WRN-34-10's flops) run in bf16, the rest stays fp32; GR_EINVAL for a net without
+ * such a layer. */
 #define GR_PREC_F32 0
 #define GR_PREC_BF16 1
 int gr_model_set_precision(gr_model* m, int precision);
 int gr_model_get_precision(const gr_model* m);
-/* Which GTSRBNet layers GR_PREC_BF16 moves to bf16: bit 1 = conv2_2, 2 = conv3_1, 3 = conv3_2, 4 = conv4_1, 5 = conv4_2,
- * 6 = fc5 + fc6 (default 0x7e = all of them).  For tests and error budgets: one layer at a time can be compared with its
+/* Which GTSRBNet layers GR_PREC_BF16 moves to bf16: bit 0 = conv2_1, 1 = conv2_2, 2 = conv3_1, 3 = conv3_2, 4 = conv4_1,
+ * 5 = conv4_2, 6 = fc5 + fc6 (default 0x7f = all of them).  For tests and error budgets: one layer at a time can be compared with its
  * restatement without the rounding-boundary flips of the layers before it. */
 int gr_model_set_bf16_layers(gr_model* m, unsigned mask);
 /* forward: x = [N,3,32,32] dev (already in the net's input range) -> logits [N,ncls] dev. */

@@ -18,10 +18,10 @@ def forward(sd, x):
     return F.linear(h, sd["fc7_1.weight"], sd["fc7_1.bias"])
 
 
-def forward_bf16(sd, x, layers=("conv2_2", "conv3_1", "conv3_2", "conv4_1", "conv4_2", "fc5_1", "fc6_1")):
-    """The GR_PREC_BF16 mode of the HIP library restated: conv2_2 .. conv4_2 take activations and weights rounded to
+def forward_bf16(sd, x, layers=("conv2_1", "conv2_2", "conv3_1", "conv3_2", "conv4_1", "conv4_2", "fc5_1", "fc6_1")):
+    """The GR_PREC_BF16 mode of the HIP library restated: conv2_1 .. conv4_2 take activations and weights rounded to
     bfloat16 (nearest even), products are exact and summed wide (float64 here, so the sum does not depend on the order;
-    the matrix cores accumulate in float32), bias / ReLU / max-pool in float32; fc5 / fc6 likewise; conv1_1, conv2_1 and fc7 stay
+    the matrix cores accumulate in float32), bias / ReLU / max-pool in float32; fc5 / fc6 likewise; conv1_1 and fc7 stay
     fp32.  A tolerance reference, not a bit-exact one."""
     def cbf(h, name):
         if name not in layers:
@@ -29,8 +29,7 @@ def forward_bf16(sd, x, layers=("conv2_2", "conv3_1", "conv3_2", "conv4_1", "con
         y = F.conv2d(h.bfloat16().double(), sd[name + ".weight"].bfloat16().double(), None, padding=2).float()
         return F.relu(y + sd[name + ".bias"][None, :, None, None])
     h = F.relu(F.conv2d(x, sd["conv1_1.weight"], sd["conv1_1.bias"]))
-    h = F.relu(F.conv2d(h, sd["conv2_1.weight"], sd["conv2_1.bias"], padding=2))
-    h = F.max_pool2d(cbf(h, "conv2_2"), 2)
+    h = F.max_pool2d(cbf(cbf(h, "conv2_1"), "conv2_2"), 2)
     h = F.max_pool2d(cbf(cbf(h, "conv3_1"), "conv3_2"), 2)
     h = F.max_pool2d(cbf(cbf(h, "conv4_1"), "conv4_2"), 2)
     def lbf(h, name):

@@ -5,8 +5,8 @@ sys.path[:0] = [ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")]
 import torch
 import gtsrb_torch_reference as G
 from graphite_amd import models, synth
-names = {1: "conv2_2", 2: "conv3_1", 3: "conv3_2", 4: "conv4_1", 5: "conv4_2", 6: "fc"}
-mask = int(os.environ.get("GRAPHITE_BF16_LAYERS", "0x7e"), 0)
+names = {0: "conv2_1", 1: "conv2_2", 2: "conv3_1", 3: "conv3_2", 4: "conv4_1", 5: "conv4_2", 6: "fc"}
+mask = int(os.environ.get("GRAPHITE_BF16_LAYERS", "0x7f"), 0)
 layers = tuple(n for l, n in names.items() if (mask >> l) & 1)
 if "fc" in layers:
     layers = tuple(n for n in layers if n != "fc") + ("fc5_1", "fc6_1")
