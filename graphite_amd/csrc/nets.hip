@@ -650,28 +650,30 @@ static int run_gtsrb_halo_bf16(gr_ctx* ctx, const Layer& L, int layer, const flo
     //                                 CIN COUT  TH  TW NIMG WM WN TM TN KBS POOL
 #define HB(...) e = launch_conv_halo_bf16<__VA_ARGS__>(p, st)
     switch (layer * 8 + v) {
-    case 1 * 8 + 0: HB( 32,  32, 16, 32, 1,  4, 1, 4, 1, 10, true ); break;    // conv2_2   (variant 0 = fastest measured)
-    case 1 * 8 + 1: HB( 32,  32,  8, 32, 1,  4, 1, 2, 1, 10, true ); break;
-    case 2 * 8 + 0: HB( 32,  64, 16, 16, 1,  2, 2, 4, 1, 10, false); break;    // conv3_1
-    case 2 * 8 + 1: HB( 32,  64, 16, 16, 1,  4, 1, 2, 2, 10, false); break;
-    case 3 * 8 + 0: HB( 64,  64, 16, 16, 1,  2, 2, 4, 1,  4, true ); break;    // conv3_2
-    case 3 * 8 + 1: HB( 64,  64, 16, 16, 1,  4, 1, 2, 2,  4, true ); break;
-    case 4 * 8 + 0: HB( 64, 128,  8,  8, 4,  4, 2, 2, 2,  4, false); break;    // conv4_1
-    case 4 * 8 + 1: HB( 64, 128,  8,  8, 2,  2, 2, 2, 2,  4, false); break;
+    // variant 0 = fastest measured (profiles/r01_bf16_tune.md): 8 wavefronts per workgroup wherever the tile allows
+    case 1 * 8 + 0: HB( 32,  32, 16, 32, 1,  8, 1, 2, 1, 10, true ); break;    // conv2_2
+    case 1 * 8 + 1: HB( 32,  32, 16, 32, 1,  8, 1, 2, 1,  2, true ); break;
+    case 1 * 8 + 2: HB( 32,  32, 32, 32, 1, 16, 1, 2, 1, 10, true ); break;
+    case 1 * 8 + 3: HB( 32,  32,  8, 32, 1,  4, 1, 2, 1,  2, true ); break;
+    case 1 * 8 + 4: HB( 32,  32, 16, 32, 1,  4, 1, 4, 1, 10, true ); break;
+    case 2 * 8 + 0: HB( 32,  64, 16, 16, 1,  2, 2, 4, 1,  2, false); break;    // conv3_1
+    case 2 * 8 + 1: HB( 32,  64, 16, 16, 1,  4, 2, 2, 1,  2, false); break;
+    case 2 * 8 + 2: HB( 32,  64, 16, 16, 2,  4, 2, 4, 1,  2, false); break;
+    case 2 * 8 + 3: HB( 32,  64,  8, 16, 1,  2, 2, 2, 1,  2, false); break;
+    case 2 * 8 + 4: HB( 32,  64, 16, 16, 1,  2, 2, 4, 1, 10, false); break;
+    case 3 * 8 + 0: HB( 64,  64, 16, 16, 1,  4, 2, 2, 1,  4, true ); break;    // conv3_2
+    case 3 * 8 + 1: HB( 64,  64, 16, 16, 1,  4, 2, 2, 1,  2, true ); break;
+    case 3 * 8 + 3: HB( 64,  64,  8, 16, 1,  2, 2, 2, 1,  4, true ); break;
+    case 3 * 8 + 4: HB( 64,  64, 16, 16, 1,  2, 2, 4, 1,  4, true ); break;
+    case 4 * 8 + 0: HB( 64, 128,  8,  8, 2,  2, 4, 2, 1,  4, false); break;    // conv4_1
+    case 4 * 8 + 1: HB( 64, 128,  8,  8, 2,  2, 4, 2, 1,  2, false); break;
+    case 4 * 8 + 2: HB( 64, 128,  8,  8, 4,  4, 4, 2, 1,  4, false); break;
+    case 4 * 8 + 3: HB( 64, 128,  8,  8, 2,  2, 2, 2, 2,  4, false); break;
+    case 4 * 8 + 4: HB( 64, 128,  8,  8, 4,  4, 2, 2, 2,  4, false); break;
     case 5 * 8 + 0: HB(128, 128,  8,  8, 2,  2, 4, 2, 1,  4, true ); break;    // conv4_2
-    case 5 * 8 + 1: HB(128, 128,  8,  8, 1,  1, 4, 2, 1,  4, true ); break;
-    case 5 * 8 + 2: HB(128, 128,  8,  8, 2,  2, 2, 2, 2,  4, true ); break;
-    // prefetch-depth variants of variant 0 (PF = 1 / 5; default 3)
-    case 1 * 8 + 3: HB( 32,  32, 16, 32, 1,  4, 1, 4, 1, 10, true , 1); break;
-    case 1 * 8 + 4: HB( 32,  32, 16, 32, 1,  4, 1, 4, 1, 10, true , 5); break;
-    case 2 * 8 + 3: HB( 32,  64, 16, 16, 1,  2, 2, 4, 1, 10, false, 1); break;
-    case 2 * 8 + 4: HB( 32,  64, 16, 16, 1,  2, 2, 4, 1, 10, false, 5); break;
-    case 3 * 8 + 3: HB( 64,  64, 16, 16, 1,  2, 2, 4, 1,  4, true , 1); break;
-    case 3 * 8 + 4: HB( 64,  64, 16, 16, 1,  2, 2, 4, 1,  4, true , 5); break;
-    case 4 * 8 + 3: HB( 64, 128,  8,  8, 4,  4, 2, 2, 2,  4, false, 1); break;
-    case 4 * 8 + 4: HB( 64, 128,  8,  8, 4,  4, 2, 2, 2,  4, false, 5); break;
-    case 5 * 8 + 3: HB(128, 128,  8,  8, 2,  2, 4, 2, 1,  4, true , 1); break;
-    case 5 * 8 + 4: HB(128, 128,  8,  8, 2,  2, 4, 2, 1,  4, true , 5); break;
+    case 5 * 8 + 1: HB(128, 128,  8,  8, 2,  2, 4, 2, 1,  2, true ); break;
+    case 5 * 8 + 3: HB(128, 128,  8,  8, 1,  1, 4, 2, 1,  4, true ); break;
+    case 5 * 8 + 4: HB(128, 128,  8,  8, 2,  2, 2, 2, 2,  4, true ); break;
     default: return gr_fail(ctx, GR_EINVAL, "conv_halo_bf16: no variant %d for layer %d", v, layer);
     }
 #undef HB
