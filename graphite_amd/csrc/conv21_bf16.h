@@ -19,11 +19,11 @@ struct Conv21BfParams {
     const float* in;        // [B,32,32,4] f32 (channel 3 is zero)
     const uint16_t* wgt;    // bf16 [10 k-blocks][2][32][8]
     const float* bias;      // [32]
-    float* out;             // [B,32,32,32] f32
+    void* out;              // [B,32,32,32] f32, or bf16 (OUT_BF)
     int B;
 };
 
-template <int TH>           // tile = TH rows x 32 columns of one image; 4 wavefronts x TM = TH/4 m-tiles (one row each)
+template <int TH, bool OUT_BF>   // tile = TH rows x 32 columns of one image; 4 wavefronts x TM = TH/4 m-tiles (one row each)
 __global__ __launch_bounds__(256) void k_conv21_bf16(Conv21BfParams p) {
     constexpr int NT = 256, TW = 32, H = 32, W = 32;
     constexpr int THH = TH + 4;
@@ -62,15 +62,15 @@ __global__ __launch_bounds__(256) void k_conv21_bf16(Conv21BfParams p) {
     {
         constexpr int NPX = THH * TWP;
         constexpr int IT = (NPX + NT - 1) / NT;
-        float4 v[IT];
+        f32x4v v[IT];                                      // native vectors: HIP's float4 struct arrays cost registers / scratch
 #pragma unroll
         for (int u = 0; u < IT; u++) {
             const int i = tid + u * NT;
             const int hy = i / TWP, hx = i % TWP;
             const int gy = y0 + hy - 2, gx = hx - 2;
-            v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+            v[u] = f32x4v{0.f, 0.f, 0.f, 0.f};
             if (i < NPX && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W)
-                v[u] = *reinterpret_cast<const float4*>(p.in + (((size_t)b * H + gy) * W + gx) * 4);
+                v[u] = *reinterpret_cast<const f32x4v*>(p.in + (((size_t)b * H + gy) * W + gx) * 4);
         }
 #pragma unroll
         for (int u = 0; u < IT; u++) {
@@ -78,7 +78,7 @@ __global__ __launch_bounds__(256) void k_conv21_bf16(Conv21BfParams p) {
             if (i < NPX) {
                 const int hy = i / TWP, hx = i % TWP;
                 bf16x4 h;
-                h[0] = (__bf16)v[u].x; h[1] = (__bf16)v[u].y; h[2] = (__bf16)v[u].z; h[3] = (__bf16)v[u].w;
+                h[0] = (__bf16)v[u][0]; h[1] = (__bf16)v[u][1]; h[2] = (__bf16)v[u][2]; h[3] = (__bf16)v[u][3];
                 *reinterpret_cast<bf16x4*>(sm + hy * ROWB + hx * 8) = h;
                 if (hx > 0) *reinterpret_cast<bf16x4*>(sm + C1 + hy * ROWB + (hx - 1) * 8) = h;
             }
@@ -115,16 +115,18 @@ __global__ __launch_bounds__(256) void k_conv21_bf16(Conv21BfParams p) {
             const int gx = (r & 3) + 8 * (r >> 2) + 4 * lh;
             float v = acc[i][r] + bias;
             v = v > 0.f ? v : 0.f;
-            p.out[(((size_t)b * H + gy) * W + gx) * 32 + lp] = v;
+            const size_t idx = (((size_t)b * H + gy) * W + gx) * 32 + lp;
+            if constexpr (OUT_BF) reinterpret_cast<__bf16*>(p.out)[idx] = (__bf16)v;
+            else reinterpret_cast<float*>(p.out)[idx] = v;
         }
     }
 }
 
-template <int TH>
+template <int TH, bool OUT_BF>
 static inline hipError_t launch_conv21_bf16(const Conv21BfParams& p, hipStream_t st) {
     const long long groups = ((long long)p.B + 7) / 8 * 8;
     const long long nblk = groups * (32 / TH);
     if (p.B <= 0 || nblk > 0x7fffffffLL) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(k_conv21_bf16<TH>, dim3((unsigned)nblk), dim3(256), 0, st, p);
+    hipLaunchKernelGGL((k_conv21_bf16<TH, OUT_BF>), dim3((unsigned)nblk), dim3(256), 0, st, p);
     return hipGetLastError();
 }

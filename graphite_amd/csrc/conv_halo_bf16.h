@@ -3,7 +3,8 @@
 //
 // Same data movement idea as conv_halo.h -- the haloed input tile is staged in LDS once per workgroup -- with the
 // operands shaped for v_mfma_f32_32x32x16_bf16 (8 k-values per lane, one ds_read_b128 each):
-//   * A: the tile is converted f32 -> bf16 (round to nearest even) while it is staged; pixel stride CIN*2+16 bytes
+//   * A: the tile is converted f32 -> bf16 (round to nearest even) while it is staged (or copied, when the producing
+//     layer already stored bf16: IN_BF / OUT_BF -- the values are the same, only the HBM traffic halves); pixel stride CIN*2+16 bytes
 //     (an odd number of 16-byte slots) and a row stride chosen so that the 16-lane groups of ds_read_b128 hit 16
 //     distinct slots for every pixel order used here (linear 16- and 8-wide tiles, 2x2 pool windows).
 //   * B: weights are packed at load as [k-block of 16][32-wide n tile][k half][cout][8 k] bf16, i.e. in the exact
@@ -34,12 +35,13 @@ __device__ __forceinline__ void bf_static_for(F&& f) {
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4v __attribute__((ext_vector_type(4)));
 
 struct HaloBfParams {
-    const float* in;        // [B,H,W,CIN] f32 NHWC
+    const void* in;         // [B,H,W,CIN] NHWC, f32 (IN_BF = false) or bf16 (IN_BF = true)
     const uint16_t* wgt;    // bf16, [K/16][COUT/32][2][32][8]
     const float* bias;      // [COUT]
-    float* out;             // [B,H,W,COUT] or pooled [B,H/2,W/2,COUT], f32
+    void* out;              // [B,H,W,COUT] or pooled [B,H/2,W/2,COUT], f32 or bf16 (OUT_BF)
     int B, H, W, relu;
 };
 
@@ -56,10 +58,18 @@ struct HaloBfGeom {
     static constexpr int NTILE = COUT / 32;
     static constexpr int STAGE_B = KBS * NTILE * 1024;
     static constexpr int LDS_BYTES = A_BYTES + 2 * STAGE_B;
+    // wavefronts per SIMD that LDS admits (HIP's second __launch_bounds__ argument) -> the register budget the
+    // compiler is asked to respect: left alone it spends 170-200 registers on some instantiations and halves the
+    // resident waves.  Capped at 4 (128 registers).
+    static constexpr int occ(int nt) {
+        const int w = (160 * 1024 / LDS_BYTES) * (nt / 64) / 4;
+        return w < 1 ? 1 : w > 4 ? 4 : w;
+    }
 };
 
-template <int CIN, int COUT, int TH, int TW, int NIMG, int WM, int WN, int TM, int TN, int KBS, bool POOL, int PF>
-__global__ __launch_bounds__(WM* WN * 64) void k_conv_halo_bf16(HaloBfParams p) {
+template <int CIN, int COUT, int TH, int TW, int NIMG, int WM, int WN, int TM, int TN, int KBS, bool POOL, int PF, bool IN_BF, bool OUT_BF>
+__global__ __launch_bounds__(WM* WN * 64, (HaloBfGeom<CIN, COUT, TH, TW, NIMG, KBS, POOL>::occ(WM * WN * 64)))
+void k_conv_halo_bf16(HaloBfParams p) {
     using G = HaloBfGeom<CIN, COUT, TH, TW, NIMG, KBS, POOL>;
     constexpr int NT = WM * WN * 64;
     constexpr int THH = G::THH, TWH = G::TWH, PSB = G::PSB, RSB = G::RSB, IMGB = G::IMGB;
@@ -119,11 +129,12 @@ __global__ __launch_bounds__(WM* WN * 64) void k_conv_halo_bf16(HaloBfParams p) 
 #pragma unroll
     for (int d = 0; d <= PF; d++) gload(breg[d], d);
 
-    // ---- stage the haloed input tile, f32 -> bf16 (zero outside the image / batch) ----
-    // Thread = (4-channel segment, pixel); the pixel walks the tile in steps of NT/SEG with incremental (x, y, image)
-    // updates: at bf16 MFMA rates the index arithmetic of this loop is a visible share of a workgroup's time.
+    // ---- stage the haloed input tile (zero outside the image / batch): f32 -> bf16 on the way, or a plain copy when
+    // the producer already stored bf16 (same values: it rounded the same f32 numbers) ----
+    // Thread = (16-byte segment of a pixel's channels, pixel); the pixel walks the tile in steps of NT/SEG.
     {
-        constexpr int SEG = CIN / 4;
+        constexpr int EPS = IN_BF ? 8 : 4;               // channels per 16-byte global segment
+        constexpr int SEG = CIN / EPS;
         static_assert(NT % SEG == 0, "segments per pixel must divide the workgroup");
         constexpr int PSTEP = NT / SEG;                   // pixels per pass
         constexpr int NPX = NIMG * THH * TWH;
@@ -133,18 +144,18 @@ __global__ __launch_bounds__(WM* WN * 64) void k_conv_halo_bf16(HaloBfParams p) 
         const int seg = tid % SEG;
         int px = tid / SEG;
         int hx = px % TWH, hy = (px / TWH) % THH, im = px / (TWH * THH);
-        const float* src = p.in + seg * 4;
+        const u32x4* src = reinterpret_cast<const u32x4*>(p.in) + seg;
 #pragma unroll
         for (int it0 = 0; it0 < IT; it0 += UB) {
-            float4 v[UB];
+            u32x4 v[UB];
             int dst[UB];
 #pragma unroll
             for (int u = 0; u < UB; u++) {
                 const int gy = y0 + hy - 2, gx = x0 + hx - 2, gb = b0 + im;
-                v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-                dst[u] = (it0 + u < IT && px < NPX) ? im * IMGB + hy * RSB + hx * PSB + seg * 8 : -1;
+                v[u] = u32x4{0u, 0u, 0u, 0u};
+                dst[u] = (it0 + u < IT && px < NPX) ? im * IMGB + hy * RSB + hx * PSB + seg * (EPS * 2) : -1;
                 if (dst[u] >= 0 && gb < p.B && (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W)
-                    v[u] = *reinterpret_cast<const float4*>(src + (((size_t)gb * p.H + gy) * p.W + gx) * CIN);
+                    v[u] = src[(((size_t)gb * p.H + gy) * p.W + gx) * SEG];
                 px += PSTEP;
                 hx += PSTEP % TWH;
                 hy += PSTEP / TWH;
@@ -154,9 +165,14 @@ __global__ __launch_bounds__(WM* WN * 64) void k_conv_halo_bf16(HaloBfParams p) 
 #pragma unroll
             for (int u = 0; u < UB; u++) {
                 if (dst[u] >= 0) {
-                    bf16x4 h;
-                    h[0] = (__bf16)v[u].x; h[1] = (__bf16)v[u].y; h[2] = (__bf16)v[u].z; h[3] = (__bf16)v[u].w;
-                    *reinterpret_cast<bf16x4*>(asm_ + dst[u]) = h;
+                    if constexpr (IN_BF) {
+                        *reinterpret_cast<u32x4*>(asm_ + dst[u]) = v[u];
+                    } else {
+                        const f32x4v f = __builtin_bit_cast(f32x4v, v[u]);   // whole vector: an element-wise bit_cast miscompiles (ROCm 7.2)
+                        bf16x4 h;
+                        h[0] = (__bf16)f[0]; h[1] = (__bf16)f[1]; h[2] = (__bf16)f[2]; h[3] = (__bf16)f[3];
+                        *reinterpret_cast<bf16x4*>(asm_ + dst[u]) = h;
+                    }
                 }
             }
         }
@@ -232,6 +248,10 @@ __global__ __launch_bounds__(WM* WN * 64) void k_conv_halo_bf16(HaloBfParams p) 
     });
 
     // ---- epilogue (conv_halo.h) ----
+    auto store_out = [&](size_t idx, float v) {
+        if constexpr (OUT_BF) reinterpret_cast<__bf16*>(p.out)[idx] = (__bf16)v;
+        else reinterpret_cast<float*>(p.out)[idx] = v;
+    };
 #pragma unroll
     for (int j = 0; j < TN; j++) {
         const int co = (wn * TN + j) * 32 + lp;
@@ -257,7 +277,7 @@ __global__ __launch_bounds__(WM* WN * 64) void k_conv_halo_bf16(HaloBfParams p) 
                     int im = w / WPI, r = w % WPI;
                     int py = (y0 >> 1) + r / WPR, px = (x0 >> 1) + r % WPR;
                     int gb = b0 + im;
-                    if (gb < p.B) p.out[(((size_t)gb * Hp + py) * Wp + px) * COUT + co] = mx;
+                    if (gb < p.B) store_out((((size_t)gb * Hp + py) * Wp + px) * COUT + co, mx);
                 }
             } else {
 #pragma unroll
@@ -268,7 +288,7 @@ __global__ __launch_bounds__(WM* WN * 64) void k_conv_halo_bf16(HaloBfParams p) 
                     if (gb < p.B) {
                         float v = acc[i][j][r] + bias;
                         if (p.relu) v = v > 0.f ? v : 0.f;
-                        p.out[(((size_t)gb * p.H + gy) * p.W + gx) * COUT + co] = v;
+                        store_out((((size_t)gb * p.H + gy) * p.W + gx) * COUT + co, v);
                     }
                 }
             }
@@ -276,13 +296,14 @@ __global__ __launch_bounds__(WM* WN * 64) void k_conv_halo_bf16(HaloBfParams p) 
     }
 }
 
-template <int CIN, int COUT, int TH, int TW, int NIMG, int WM, int WN, int TM, int TN, int KBS, bool POOL, int PF = 3>
+template <int CIN, int COUT, int TH, int TW, int NIMG, int WM, int WN, int TM, int TN, int KBS, bool POOL, int PF = 3, bool IN_BF = false,
+          bool OUT_BF = false>
 static inline hipError_t launch_conv_halo_bf16(const HaloBfParams& p, hipStream_t st) {
     using G = HaloBfGeom<CIN, COUT, TH, TW, NIMG, KBS, POOL>;
     constexpr size_t smem = G::LDS_BYTES;
     static_assert(smem <= 160 * 1024, "LDS");
     if (p.H % TH || p.W % TW) return hipErrorInvalidValue;
-    auto kern = k_conv_halo_bf16<CIN, COUT, TH, TW, NIMG, WM, WN, TM, TN, KBS, POOL, PF>;
+    auto kern = k_conv_halo_bf16<CIN, COUT, TH, TW, NIMG, WM, WN, TM, TN, KBS, POOL, PF, IN_BF, OUT_BF>;
     static bool attr_set[64] = {false};                  // the attribute is per device
     int dev_ = 0;
     if (hipGetDevice(&dev_) != hipSuccess || dev_ < 0 || dev_ >= 64) return hipErrorInvalidDevice;

@@ -11,14 +11,14 @@
 #include "conv_halo_bf16.h"
 
 struct GemmBfParams {
-    const float* a;         // [M][K]
+    const void* a;          // [M][K] f32, or bf16 (IN_BF)
     const uint16_t* w;      // packed bf16
     const float* bias;      // [N]
-    float* c;               // [M][N]
+    void* c;                // [M][N] f32, or bf16 (OUT_BF)
     int M, N, K, relu;
 };
 
-template <int WM, int WN, int TM, int TN, int BK>
+template <int WM, int WN, int TM, int TN, int BK, bool IN_BF, bool OUT_BF>
 __global__ __launch_bounds__(WM* WN * 64, 2) void k_gemm_bf16(GemmBfParams p) {
     constexpr int NT = WM * WN * 64;
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
@@ -26,9 +26,10 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void k_gemm_bf16(GemmBfParams p) {
     constexpr int A_ST = BM * ASTR;
     constexpr int KBS = BK / 16;
     constexpr int B_ST = KBS * (BN / 32) * 1024;
-    constexpr int AV = BM * (BK / 4) / NT;                // float4 loads per thread and stage
+    constexpr int EPS = IN_BF ? 8 : 4;                    // A elements per 16-byte load
+    constexpr int AV = BM * (BK / EPS) / NT;              // 16-byte A loads per thread and stage
     constexpr int BV = B_ST / 16 / NT;                    // 16-byte loads per thread and stage
-    static_assert(BM * (BK / 4) % NT == 0 && (B_ST / 16) % NT == 0, "stage loads must divide evenly");
+    static_assert(BM * (BK / EPS) % NT == 0 && (B_ST / 16) % NT == 0, "stage loads must divide evenly");
     static_assert((ASTR / 16) % 2 == 1, "A row stride must be an odd number of 16-byte slots");
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_g[];
@@ -43,18 +44,17 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void k_gemm_bf16(GemmBfParams p) {
     const int m0 = (blockIdx.x / nbn) * BM, n0 = (blockIdx.x % nbn) * BN;   // consecutive workgroups share the A rows
     const int NS = p.K / BK;
 
-    typedef float f32x4 __attribute__((ext_vector_type(4)));
-    f32x4 areg[2][AV];
+    u32x4 areg[2][AV];
     u32x4 breg[2][BV];
     const u32x4* wg = reinterpret_cast<const u32x4*>(p.w);
-    auto gload = [&](f32x4 (&ar)[AV], u32x4 (&br)[BV], int s) {
+    auto gload = [&](u32x4 (&ar)[AV], u32x4 (&br)[BV], int s) {
         if (s >= NS) s = NS - 1;                          // clamped, never conditional (conv_halo.h)
 #pragma unroll
         for (int v = 0; v < AV; v++) {
             const int f = tid + v * NT;
-            int row = m0 + f / (BK / 4);
+            int row = m0 + f / (BK / EPS);
             if (row >= p.M) row = p.M - 1;
-            ar[v] = *reinterpret_cast<const f32x4*>(p.a + (size_t)row * p.K + s * BK + (f % (BK / 4)) * 4);
+            ar[v] = reinterpret_cast<const u32x4*>(p.a)[((size_t)row * p.K + s * BK) / EPS + f % (BK / EPS)];
         }
 #pragma unroll
         for (int v = 0; v < BV; v++) {
@@ -63,13 +63,19 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void k_gemm_bf16(GemmBfParams p) {
             br[v] = wg[((size_t)(s * KBS + c) * (p.N / 32) + n0 / 32) * 64 + r];
         }
     };
-    auto lstore = [&](const f32x4 (&ar)[AV], const u32x4 (&br)[BV], int buf) {
+    auto lstore = [&](const u32x4 (&ar)[AV], const u32x4 (&br)[BV], int buf) {
 #pragma unroll
         for (int v = 0; v < AV; v++) {
             const int f = tid + v * NT;
-            bf16x4 h;
-            h[0] = (__bf16)ar[v][0]; h[1] = (__bf16)ar[v][1]; h[2] = (__bf16)ar[v][2]; h[3] = (__bf16)ar[v][3];
-            *reinterpret_cast<bf16x4*>(asm_ + buf * A_ST + (f / (BK / 4)) * ASTR + (f % (BK / 4)) * 8) = h;
+            unsigned char* d = asm_ + buf * A_ST + (f / (BK / EPS)) * ASTR + (f % (BK / EPS)) * (EPS * 2);
+            if constexpr (IN_BF) {
+                *reinterpret_cast<u32x4*>(d) = ar[v];
+            } else {
+                const f32x4v fv = __builtin_bit_cast(f32x4v, ar[v]);    // whole vector: an element-wise bit_cast miscompiles (ROCm 7.2)
+                bf16x4 h;
+                h[0] = (__bf16)fv[0]; h[1] = (__bf16)fv[1]; h[2] = (__bf16)fv[2]; h[3] = (__bf16)fv[3];
+                *reinterpret_cast<bf16x4*>(d) = h;
+            }
         }
 #pragma unroll
         for (int v = 0; v < BV; v++) *reinterpret_cast<u32x4*>(bsm + buf * B_ST + (tid + v * NT) * 16) = br[v];
@@ -135,19 +141,20 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void k_gemm_bf16(GemmBfParams p) {
                 if (m < p.M) {
                     float v = acc[i][j][r] + bias;
                     if (p.relu) v = v > 0.f ? v : 0.f;
-                    p.c[(size_t)m * p.N + n] = v;
+                    if constexpr (OUT_BF) reinterpret_cast<__bf16*>(p.c)[(size_t)m * p.N + n] = (__bf16)v;
+                    else reinterpret_cast<float*>(p.c)[(size_t)m * p.N + n] = v;
                 }
             }
     }
 }
 
-template <int WM, int WN, int TM, int TN, int BK>
+template <int WM, int WN, int TM, int TN, int BK, bool IN_BF = false, bool OUT_BF = false>
 static inline hipError_t launch_gemm_bf16(const GemmBfParams& p, hipStream_t st) {
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
     constexpr size_t smem = 2 * (size_t)BM * (BK * 2 + 16) + 2 * (size_t)(BK / 16) * (BN / 32) * 1024;
     static_assert(smem <= 160 * 1024, "LDS");
     if (p.M <= 0 || p.N % BN || p.K % BK || p.K / BK < 2) return hipErrorInvalidValue;
-    auto kern = k_gemm_bf16<WM, WN, TM, TN, BK>;
+    auto kern = k_gemm_bf16<WM, WN, TM, TN, BK, IN_BF, OUT_BF>;
     static bool attr_set[64] = {false};                   // the attribute is per device
     int dev_ = 0;
     if (hipGetDevice(&dev_) != hipSuccess || dev_ < 0 || dev_ >= 64) return hipErrorInvalidDevice;

@@ -38,7 +38,8 @@ struct gr_model {
     gr_ctx* ctx = nullptr;
     int kind = 0;            // 1 = GTSRBNet, 2 = WideResNet
     int precision = GR_PREC_F32;
-    int bf16_mask = 0x7f;    // layers that GR_PREC_BF16 runs in bf16: bit 0 = conv2_1 .. bit 5 = conv4_2, bit 6 = fc5 + fc6
+    int bf16_mask = 0x7f;    // layers that GR_PREC_BF16 runs in bf16: bit 0 = conv2_1 .. bit 5 = conv4_2, bit 6 = fc5 + fc6;
+                             // bit 7: keep the activations between them f32 in HBM (they are bf16 when all 7 layers are)
     int ncls = 0;
     std::vector<void*> allocs;
     // GTSRBNet
@@ -344,7 +345,7 @@ extern "C" int gr_model_set_precision(gr_model* m, int precision) {
 extern "C" int gr_model_get_precision(const gr_model* m) { return m ? m->precision : GR_EINVAL; }
 extern "C" int gr_model_set_bf16_layers(gr_model* m, unsigned mask) {
     if (!m) return GR_EINVAL;
-    if (mask & ~0x7fu) return gr_fail(m->ctx, GR_EINVAL, "gr_model_set_bf16_layers: mask 0x%x has bits outside 0x7f", mask);
+    if (mask & ~0xffu) return gr_fail(m->ctx, GR_EINVAL, "gr_model_set_bf16_layers: mask 0x%x has bits outside 0xff", mask);
     m->bf16_mask = (int)mask;
     return GR_OK;
 }
@@ -635,13 +636,14 @@ static int run_gtsrb_halo(gr_ctx* ctx, const Layer& L, int layer, const float* i
 }
 
 // GTSRBNet's conv2_2 .. conv4_2 on the bf16 matrix cores (conv_halo_bf16.h), f32 activations in and out.
-static int run_gtsrb_halo_bf16(gr_ctx* ctx, const Layer& L, int layer, const float* in, int B, int H, float* out, hipStream_t st) {
+static int run_gtsrb_halo_bf16(gr_ctx* ctx, const Layer& L, int layer, const float* in, int B, int H, float* out, hipStream_t st,
+                               bool in_bf = false, bool out_bf = false) {      // activations stored as bf16 (variant 0 only)
     HaloBfParams p;
     p.in = in; p.wgt = L.wbf; p.bias = L.bias; p.out = out; p.B = B; p.H = H; p.W = H; p.relu = 1;
     const bool pool = layer == 1 || layer == 3 || layer == 5;
     const double M = (double)B * H * H;
     const double flops = 2.0 * M * L.Cout * 25 * L.CinT;
-    const double bytes = 4.0 * (M * L.CinT + (pool ? M / 4 : M) * L.Cout) + 2.0 * 25.0 * L.CinT * L.Cout;
+    const double bytes = (in_bf ? 2.0 : 4.0) * M * L.CinT + (out_bf ? 2.0 : 4.0) * (pool ? M / 4 : M) * L.Cout + 2.0 * 25.0 * L.CinT * L.Cout;
     char pname[64];
     snprintf(pname, sizeof(pname), "k_conv_halo_bf16<conv%d_%d>", 2 + layer / 2, 1 + layer % 2);
     ProfScope ps_(ctx, pname, st, flops, bytes);
@@ -649,6 +651,20 @@ static int run_gtsrb_halo_bf16(gr_ctx* ctx, const Layer& L, int layer, const flo
     const int v = bf16_variant(layer);
     //                                 CIN COUT  TH  TW NIMG WM WN TM TN KBS POOL
 #define HB(...) e = launch_conv_halo_bf16<__VA_ARGS__>(p, st)
+    if (in_bf || out_bf) {              // variant 0 of conv4_1 / conv4_2 with bf16 activations on either side
+#define HB4(...)                                                                                                   \
+        do {                                                                                                       \
+            if (in_bf && out_bf) HB(__VA_ARGS__, 3, true, true);                                                   \
+            else if (in_bf) HB(__VA_ARGS__, 3, true, false);                                                       \
+            else HB(__VA_ARGS__, 3, false, true);                                                                  \
+        } while (0)
+        switch (layer) {
+        case 4: HB4( 64, 128,  8,  8, 2,  2, 4, 2, 1,  4, false); break;
+        case 5: HB4(128, 128,  8,  8, 2,  2, 4, 2, 1,  4, true ); break;
+        default: return gr_fail(ctx, GR_EINVAL, "conv_halo_bf16: layer %d", layer);
+        }
+#undef HB4
+    } else
     switch (layer * 8 + v) {
     // variant 0 = fastest measured (profiles/r01_bf16_tune.md): 8 wavefronts per workgroup wherever the tile allows
     case 1 * 8 + 0: HB( 32,  32, 16, 32, 1,  8, 1, 2, 1, 10, true ); break;    // conv2_2
@@ -682,17 +698,22 @@ static int run_gtsrb_halo_bf16(gr_ctx* ctx, const Layer& L, int layer, const flo
 }
 
 // fc5 / fc6 of the bf16 mode (gemm_bf16.h)
-static int run_fc_bf16(gr_ctx* ctx, const Layer& L, const char* name, const float* in, int M, float* out, hipStream_t st) {
+static int run_fc_bf16(gr_ctx* ctx, const Layer& L, const char* name, const float* in, int M, float* out, hipStream_t st,
+                       bool in_bf = false, bool out_bf = false) {
     GemmBfParams p;
     p.a = in; p.w = L.wbf; p.bias = L.bias; p.c = out; p.M = M; p.N = L.Cout; p.K = L.CinT; p.relu = 1;
     char pname[64];
     snprintf(pname, sizeof(pname), "k_gemm_bf16<%s>", name);
     ProfScope ps_(ctx, pname, st, 2.0 * M * L.Cout * L.CinT, 4.0 * M * (L.CinT + L.Cout) + 2.0 * L.CinT * L.Cout);
-    hipError_t e = launch_gemm_bf16<2, 2, 2, 2, 64>(p, st);
+    hipError_t e = in_bf ? (out_bf ? launch_gemm_bf16<2, 2, 2, 2, 64, true, true>(p, st) : launch_gemm_bf16<2, 2, 2, 2, 64, true, false>(p, st))
+                         : (out_bf ? launch_gemm_bf16<2, 2, 2, 2, 64, false, true>(p, st) : launch_gemm_bf16<2, 2, 2, 2, 64>(p, st));
     if (e != hipSuccess) return gr_fail(ctx, GR_EHIP, "gemm_bf16 launch (%s): %s", name, hipGetErrorString(e));
     return GR_OK;
 }
 
+// Measured per link (profiles/r01_bf16_tune.md): a bf16 INPUT costs the Cin <= 64 conv kernels registers and resident waves
+// (conv2_2 +0.9 ms, conv3_1 +0.9, conv3_2 +0.6, conv4_1 +0.3 per 32,000 images), so only the last three links are bf16.
+#define BF16_LINKS_DEFAULT 0x70
 static bool use_igemm_convs() {      // GRAPHITE_CONV=igemm selects the im2col-chunk kernels for A/B runs
     static int v = -1;
     if (v < 0) { const char* e = getenv("GRAPHITE_CONV"); v = (e && strcmp(e, "igemm") == 0) ? 1 : 0; }
@@ -711,14 +732,25 @@ static int gtsrb_forward(gr_ctx* ctx, gr_model* m, const float* x, int N, float*
     int rc;
     if (m->precision == GR_PREC_BF16) {
         const int mask = m->bf16_mask;
+        // All layers in bf16 (the default): some of the activations between them are STORED as bf16 -- the values are
+        // the ones the consumer would have rounded to anyway (same f32 number, same nearest-even rounding; max-pool
+        // commutes with it), so the logits are bit-identical to the f32-activation pipeline (mask bit 7 keeps that one,
+        // for the test).  A and Bf are reused as half-filled bf16 buffers.
+        // links: bit i = the activation between layer i and layer i+1 (4: conv4_1 -> conv4_2, 5: conv4_2 -> fc5,
+        // 6: fc5 -> fc6) is stored as bf16.  GRAPHITE_BF16_LINKS overrides the default (tuning).
+        static int links_env = -1;
+        if (links_env < 0) { const char* e = getenv("GRAPHITE_BF16_LINKS"); links_env = e ? (int)strtol(e, nullptr, 0) & 0x70 : BF16_LINKS_DEFAULT; }
+        const int links = (mask & 0xff) == 0x7f ? links_env : 0;
+        auto lk = [&](int i) { return ((links >> i) & 1) != 0; };
         auto conv = [&](int l, const float* in, int H, float* out) {
-            return (mask >> l) & 1 ? run_gtsrb_halo_bf16(ctx, m->g[l], l, in, N, H, out, st) : run_gtsrb_halo(ctx, m->g[l], l, in, N, H, out, st);
+            return (mask >> l) & 1 ? run_gtsrb_halo_bf16(ctx, m->g[l], l, in, N, H, out, st, lk(l - 1), lk(l))
+                                   : run_gtsrb_halo(ctx, m->g[l], l, in, N, H, out, st);
         };
         if (mask & 1) {
             Conv21BfParams q;
             q.in = x4; q.wgt = m->g[0].wbf; q.bias = m->g[0].bias; q.out = A; q.B = N;
-            ProfScope ps_(ctx, "k_conv21_bf16<conv2_1>", st, 2.0 * N * 1024 * 32 * 75, 4.0 * N * 1024 * (3 + 32));
-            hipError_t e = launch_conv21_bf16<16>(q, st);
+            ProfScope ps_(ctx, "k_conv21_bf16<conv2_1>", st, 2.0 * N * 1024 * 32 * 75, 4.0 * N * 1024 * (3 + (lk(0) ? 16 : 32)));
+            hipError_t e = lk(0) ? launch_conv21_bf16<16, true>(q, st) : launch_conv21_bf16<16, false>(q, st);
             if (e != hipSuccess) return gr_fail(ctx, GR_EHIP, "conv21_bf16 launch: %s", hipGetErrorString(e));
         } else if ((rc = run_gtsrb_halo(ctx, m->g[0], 0, x4, N, 32, A, st))) return rc;
         if ((rc = conv(1, A, 32, Bf))) return rc;
@@ -727,8 +759,8 @@ static int gtsrb_forward(gr_ctx* ctx, gr_model* m, const float* x, int N, float*
         if ((rc = conv(4, Bf, 8, A))) return rc;
         if ((rc = conv(5, A, 8, Bf))) return rc;
         if (mask & 0x40) {                                                                         // bit 6: fc5 / fc6
-            if ((rc = run_fc_bf16(ctx, m->g[6], "fc5", Bf, N, A, st))) return rc;
-            if ((rc = run_fc_bf16(ctx, m->g[7], "fc6", A, N, Bf, st))) return rc;
+            if ((rc = run_fc_bf16(ctx, m->g[6], "fc5", Bf, N, A, st, lk(5), lk(6)))) return rc;
+            if ((rc = run_fc_bf16(ctx, m->g[7], "fc6", A, N, Bf, st, lk(6), false))) return rc;     // fc7 (fp32) reads f32
         } else {
             if ((rc = run_conv(ctx, m->g[6], Bf, N, 1, 1, nullptr, nullptr, A, nullptr, true, false, st))) return rc;     // fc5
             if ((rc = run_conv(ctx, m->g[7], A, N, 1, 1, nullptr, nullptr, Bf, nullptr, true, false, st))) return rc;     // fc6

@@ -131,7 +131,8 @@ int gr_model_num_classes(const gr_model* m);
 int gr_model_set_precision(gr_model* m, int precision);
 int gr_model_get_precision(const gr_model* m);
 /* Which GTSRBNet layers GR_PREC_BF16 moves to bf16: bit 0 = conv2_1, 1 = conv2_2, 2 = conv3_1, 3 = conv3_2, 4 = conv4_1,
- * 5 = conv4_2, 6 = fc5 + fc6 (default 0x7f = all of them).  For tests and error budgets: one layer at a time can be compared with its
+ * 5 = conv4_2, 6 = fc5 + fc6 (default 0x7f = all of them; the activations conv4_1 -> conv4_2 -> fc5 -> fc6 are then stored
+ * as bf16, which does not change a single logit: bit 7 keeps them f32 so that a test can show it).  For tests and error budgets: one layer at a time can be compared with its
  * restatement without the rounding-boundary flips of the layers before it. */
 int gr_model_set_bf16_layers(gr_model* m, unsigned mask);
 /* forward: x = [N,3,32,32] dev (already in the net's input range) -> logits [N,ncls] dev. */

@@ -1,4 +1,4 @@
-"""Which layer of the bf16 mode deviates from the bf16-operand restatement? (GRAPHITE_BF16_LAYERS is read once per process.)"""
+"""Which layer of the bf16 mode deviates from the bf16-operand restatement? (GRAPHITE_BF16_LAYERS = layer mask, see gr_model_set_bf16_layers.)"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")]
@@ -16,6 +16,7 @@ torch.manual_seed(0)
 x = torch.rand(int(sys.argv[1]) if len(sys.argv) > 1 else 16, 3, 32, 32) - 0.5
 f32 = model.forward(x).cpu()
 model.set_precision("bf16")
+model.hip_model.set_bf16_layers(mask)
 got = model.forward(x).cpu()
 tsd = {k: torch.as_tensor(v) for k, v in sd.items()}
 ref = G.forward_bf16(tsd, x, layers)

@@ -91,6 +91,23 @@ def test_bf16_mode_end_to_end(net, n):
     assert float(e[-1]) <= MODE_MAX and float(e32[-1]) <= MODE_MAX
 
 
+def test_bf16_activations_in_hbm_do_not_change_a_logit(net):
+    """Default mask 0x7f: the layers hand bf16 activations to each other; mask 0xff keeps them f32 in HBM and lets the
+    consumer round.  Same f32 values, same rounding: the logits must be bit-identical (also for ragged batch sizes)."""
+    model, _, x = net
+    model.set_precision("bf16")
+    try:
+        for n in (1, 7, 120):
+            a = model.forward(x[:n]).cpu()
+            model.hip_model.set_bf16_layers(0xff)
+            b = model.forward(x[:n]).cpu()
+            model.hip_model.set_bf16_layers(0x7f)
+            assert torch.equal(a, b)
+    finally:
+        model.hip_model.set_bf16_layers(0x7f)
+        model.set_precision("f32")
+
+
 def test_bf16_labels_and_hit_counts_close_to_fp32():
     from graphite_amd import engine
     case = gtsrb_case(num_xforms=100)
@@ -114,7 +131,7 @@ def test_bf16_precision_errors():
         g.set_precision("fp8")
     lib = _hip.load_library()
     assert lib.gr_model_set_precision(g.hip_model._h, 7) == -1          # GR_EINVAL
-    assert lib.gr_model_set_bf16_layers(g.hip_model._h, 0x80) == -1          # GR_EINVAL
+    assert lib.gr_model_set_bf16_layers(g.hip_model._h, 0x100) == -1         # GR_EINVAL
     assert g.hip_model.precision == "f32"
 
 
