@@ -474,6 +474,7 @@ static int run_conv(gr_ctx* ctx, const Layer& L, const float* in, int B, int H, 
             case 0: HCB( 8, 16, 1,  4, 1, 5, 2); break;
             case 1: HCB(16, 16, 1,  4, 2, 5, 2); break;
             case 2: HCB( 8, 16, 1,  4, 1, 5, 3); break;
+            case 3: HCB(16, 16, 1,  8, 1, 5, 2); break;
             default: return gr_fail(ctx, GR_EINVAL, "conv_halo_cc_bf16: no variant %d", v);
             }
         } else {
@@ -481,6 +482,7 @@ static int run_conv(gr_ctx* ctx, const Layer& L, const float* in, int B, int H, 
             case 0: HCB( 8,  8, 2,  4, 1, 5, 2); break;
             case 1: HCB( 8,  8, 4,  4, 2, 5, 2); break;
             case 2: HCB( 8,  8, 2,  4, 1, 5, 3); break;
+            case 3: HCB( 8,  8, 4,  8, 1, 5, 2); break;
             default: return gr_fail(ctx, GR_EINVAL, "conv_halo_cc_bf16: no variant %d", v);
             }
         }
