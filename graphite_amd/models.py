@@ -48,7 +48,7 @@ class _HipClassifier:
         return self._require()
 
     def set_precision(self, precision):
-        """'f32' (default, the bit-exact parity path) or 'bf16' (throughput mode, GTSRBNet only): see gr_model_set_precision."""
+        """'f32' (default, the bit-exact parity path) or 'bf16' (throughput mode, bf16 operands with f32 accumulation): see gr_model_set_precision."""
         self._require().set_precision(precision)
         return self
 
