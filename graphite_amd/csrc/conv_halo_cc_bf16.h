@@ -1,4 +1,4 @@
-// conv_halo_cc_bf16.h -- bf16 MFMA convolution for WideResNet's stride-1 3x3 convs (Cin, Cout multiples of 160 / 32):
+// conv_halo_cc_bf16.h -- bf16 MFMA convolution for WideResNet's 3x3 convs, stride 1 and 2 (Cin, Cout multiples of 32 / 160):
 // the bf16 "throughput mode" twin of conv_halo_cc.h (NOT the parity path).
 //
 // As conv_halo_cc.h the contraction is walked in channel chunks of CC = 32, k = (chunk, ky, kx, ci mod 32), because a
@@ -18,32 +18,40 @@
 struct HaloCcBfParams {
     const float* in;        // [B,H,W,Cin] f32 NHWC
     const uint16_t* wgt;    // bf16, [K/16][Cout/32][2][32][8], k = (chunk, tap, ci%32)
-    const float* res;       // [B,H,W,Cout] or null
+    const float* res;       // [B,H/stride,W/stride,Cout] or null
     const float* scale;     // [Cout] folded BN of the consumer, or null
     const float* shift;
     float* out_raw;         // [B,H,W,Cout] or null
     float* out_act;         // [B,H,W,Cout] or null
-    int B, H, W, Cin, Cout;
+    int B, H, W, Cin, Cout; // H, W: input size
 };
 
-template <int TH, int TW, int NIMG>
+// STRIDE 1: the slice is one (TH+2) x (TW+2) image per input image.  STRIDE 2 (pad 1): output (y, x) reads input
+// (2y+ky-1, 2x+kx-1), so the (2TH+1) x (2TW+1) input region is stored as four PARITY PLANES of (TH+1) x (TW+1) pixels
+// (row parity, column parity of the region index): tap (ky, kx) then reads plane (ky&1, kx&1) at (y + ky/2, x + kx/2),
+// a stride-1 walk inside the plane with the same conflict-free ds_read_b128 pattern as the stride-1 kernel.
+template <int TH, int TW, int NIMG, int STRIDE>
 struct HaloCcBfGeom {
     static constexpr int CC = 32;
-    static constexpr int THH = TH + 2, TWH = TW + 2;
+    static constexpr int THH = STRIDE == 1 ? TH + 2 : 2 * TH + 1;     // input region walked by the staging loop
+    static constexpr int TWH = STRIDE == 1 ? TW + 2 : 2 * TW + 1;
+    static constexpr int PH = STRIDE == 1 ? TH + 2 : TH + 1;          // rows / columns of one LDS plane
+    static constexpr int PW = STRIDE == 1 ? TW + 2 : TW + 1;
     static constexpr int PSB = CC * 2 + 16;
     static constexpr int RWANT = TW == 8 ? 8 : 0;
-    static constexpr int RS0 = TWH * PSB;
+    static constexpr int RS0 = PW * PSB;
     static constexpr int RSB = RS0 + ((RWANT - (RS0 / 16) % 16 + 16) % 16) * 16;
-    static constexpr int IMGB = THH * RSB;
+    static constexpr int PLB = PH * RSB;                              // bytes of one plane
+    static constexpr int IMGB = (STRIDE == 1 ? 1 : 4) * PLB;
     static constexpr int A_BYTES = NIMG * IMGB;
 };
 
 // WM wavefronts x TM 32-pixel m-tiles cover the NIMG x TH x TW pixels; every wavefront holds TN n-tiles (N = TN*32).
-template <int TH, int TW, int NIMG, int WM, int TM, int TN, int OCC>
+template <int TH, int TW, int NIMG, int WM, int TM, int TN, int OCC, int STRIDE>
 __global__ __launch_bounds__(WM * 64, OCC) void k_conv_halo_cc_bf16(HaloCcBfParams p) {
-    using G = HaloCcBfGeom<TH, TW, NIMG>;
+    using G = HaloCcBfGeom<TH, TW, NIMG, STRIDE>;
     constexpr int CC = 32, NT = WM * 64;
-    constexpr int THH = G::THH, TWH = G::TWH, PSB = G::PSB, RSB = G::RSB, IMGB = G::IMGB;
+    constexpr int THH = G::THH, TWH = G::TWH, PSB = G::PSB, RSB = G::RSB, IMGB = G::IMGB, PLB = G::PLB;
     constexpr int KBS = CC / 16;                         // k-blocks per stage (one tap)
     constexpr int STAGE_B = KBS * TN * 1024;
     constexpr int SV = STAGE_B / 16, TV = TN * 64;       // vectors per stage / per k-block
@@ -61,7 +69,8 @@ __global__ __launch_bounds__(WM * 64, OCC) void k_conv_halo_cc_bf16(HaloCcBfPara
     const int tid = threadIdx.x;
     const int wave = tid >> 6, lane = tid & 63;
     const int lp = lane & 31, lh = lane >> 5;
-    const int tiles_x = p.W / TW, tiles_y = p.H / TH;
+    const int Ho = p.H / STRIDE, Wo = p.W / STRIDE;     // p.H, p.W: input; tiles are output tiles
+    const int tiles_x = Wo / TW, tiles_y = Ho / TH;
     int bid, ntile;                                      // XCD-aware order, as conv_halo_cc.h
     {
         const int tpi = tiles_x * tiles_y, groups = (p.B + NIMG - 1) / NIMG, nts = p.Cout / (TN * 32);
@@ -111,7 +120,7 @@ __global__ __launch_bounds__(WM * 64, OCC) void k_conv_halo_cc_bf16(HaloCcBfPara
         int px = px0, hx = px0 % TWH, hy = (px0 / TWH) % THH, im = px0 / (TWH * THH);
 #pragma unroll
         for (int u = 0; u < AIT; u++) {
-            const int gy = y0 + hy - 1, gx = x0 + hx - 1, gb = b0 + im;
+            const int gy = STRIDE * y0 + hy - 1, gx = STRIDE * x0 + hx - 1, gb = b0 + im;
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
             if (px < NPX && gb < p.B && (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W)
                 v = *reinterpret_cast<const f32x4*>(src + (((size_t)gb * p.H + gy) * p.W + gx) * p.Cin);
@@ -128,7 +137,9 @@ __global__ __launch_bounds__(WM * 64, OCC) void k_conv_halo_cc_bf16(HaloCcBfPara
             if (px < NPX) {
                 bf16x4 h;
                 h[0] = (__bf16)areg[u][0]; h[1] = (__bf16)areg[u][1]; h[2] = (__bf16)areg[u][2]; h[3] = (__bf16)areg[u][3];
-                *reinterpret_cast<bf16x4*>(asm_ + im * IMGB + hy * RSB + hx * PSB + seg * 8) = h;
+                const int off = STRIDE == 1 ? hy * RSB + hx * PSB
+                                            : ((hy & 1) * 2 + (hx & 1)) * PLB + (hy >> 1) * RSB + (hx >> 1) * PSB;
+                *reinterpret_cast<bf16x4*>(asm_ + im * IMGB + off + seg * 8) = h;
             }
             px += PSTEP; hx += PSTEP % TWH; hy += PSTEP / TWH;
             if (hx >= TWH) { hx -= TWH; hy++; }
@@ -167,7 +178,10 @@ __global__ __launch_bounds__(WM * 64, OCC) void k_conv_halo_cc_bf16(HaloCcBfPara
             constexpr int t = decltype(tc)::value;
             constexpr int slot = (t + 1) % 3;             // ring slot of stage s+1 (9 stages per chunk: s % 3 == t % 3)
             const int s = ch * 9 + t;
-            const unsigned char* at = asm_ + (t / 3) * RSB + (t % 3) * PSB;
+            constexpr int ky = t / 3, kx = t % 3;
+            constexpr int toff = STRIDE == 1 ? ky * RSB + kx * PSB
+                                             : ((ky & 1) * 2 + (kx & 1)) * PLB + (ky >> 1) * RSB + (kx >> 1) * PSB;
+            const unsigned char* at = asm_ + toff;
             const unsigned char* bb = bsm + (s & 1) * STAGE_B + lane * 16;
 #pragma unroll
             for (int c = 0; c < KBS; c++) {
@@ -206,7 +220,7 @@ __global__ __launch_bounds__(WM * 64, OCC) void k_conv_halo_cc_bf16(HaloCcBfPara
                 const int im = l / (TH * TW), q = l % (TH * TW);
                 const int gy = y0 + q / TW, gx = x0 + q % TW, gb = b0 + im;
                 if (gb >= p.B) continue;
-                const size_t row = (((size_t)gb * p.H + gy) * p.W + gx) * p.Cout;
+                const size_t row = (((size_t)gb * Ho + gy) * Wo + gx) * p.Cout;
                 float v = acc[i][j][r];
                 if (p.res) v = v + p.res[row + co];
                 if (p.out_raw) p.out_raw[row + co] = v;
@@ -219,13 +233,13 @@ __global__ __launch_bounds__(WM * 64, OCC) void k_conv_halo_cc_bf16(HaloCcBfPara
     }
 }
 
-template <int TH, int TW, int NIMG, int WM, int TM, int TN, int OCC>
+template <int TH, int TW, int NIMG, int WM, int TM, int TN, int OCC, int STRIDE = 1>
 static inline hipError_t launch_conv_halo_cc_bf16(const HaloCcBfParams& p, hipStream_t st) {
-    using G = HaloCcBfGeom<TH, TW, NIMG>;
+    using G = HaloCcBfGeom<TH, TW, NIMG, STRIDE>;
     constexpr size_t smem = G::A_BYTES + 2 * (size_t)(2 * TN * 1024);
     static_assert(smem <= 160 * 1024, "LDS");
-    if (p.H % TH || p.W % TW || p.Cin % 32 || p.Cout % (TN * 32) || (p.out_act && !(p.scale && p.shift))) return hipErrorInvalidValue;
-    auto kern = k_conv_halo_cc_bf16<TH, TW, NIMG, WM, TM, TN, OCC>;
+    if (p.H % (TH * STRIDE) || p.W % (TW * STRIDE) || p.Cin % 32 || p.Cout % (TN * 32) || (p.out_act && !(p.scale && p.shift))) return hipErrorInvalidValue;
+    auto kern = k_conv_halo_cc_bf16<TH, TW, NIMG, WM, TM, TN, OCC, STRIDE>;
     static bool attr_set[64] = {false};                  // the attribute is per device
     int dev_ = 0;
     if (hipGetDevice(&dev_) != hipSuccess || dev_ < 0 || dev_ >= 64) return hipErrorInvalidDevice;
@@ -237,7 +251,7 @@ static inline hipError_t launch_conv_halo_cc_bf16(const HaloCcBfParams& p, hipSt
     }
     long long groups = (p.B + NIMG - 1) / NIMG;
     groups = (groups + 7) / 8 * 8;
-    const long long nblk = groups * (p.H / TH) * (p.W / TW) * (p.Cout / (TN * 32));
+    const long long nblk = groups * (p.H / STRIDE / TH) * (p.W / STRIDE / TW) * (p.Cout / (TN * 32));
     if (nblk > 0x7fffffffLL) return hipErrorInvalidValue;
     hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(WM * 64), smem, st, p);
     return hipGetLastError();

@@ -296,7 +296,7 @@ extern "C" int gr_model_load_wrn(gr_ctx* ctx, const float* const* t, const int64
             ti += 4;
             if (!rc) rc = expect(ctx, numel, ti, (int64_t)b.cout * b.cin * 9);
             if (!rc) rc = make_layer(m, &b.conv1, t[ti], nullptr, b.cout, b.cin, 3, 3, b.stride, 1);
-            if (!rc && b.stride == 1 && b.cin % 32 == 0 && b.cout % 160 == 0) rc = make_layer_bf16_cc(m, &b.conv1, t[ti], b.cout, b.cin);
+            if (!rc && b.cin % 32 == 0 && b.cout % 160 == 0) rc = make_layer_bf16_cc(m, &b.conv1, t[ti], b.cout, b.cin);   // stride 1 and 2
             ti++;
             for (int q = 0; q < 4 && !rc; q++) rc = expect(ctx, numel, ti + q, b.cout);
             if (!rc) rc = make_bn(m, &b.bn2, t[ti], t[ti + 1], t[ti + 2], t[ti + 3], b.cout);
@@ -459,17 +459,21 @@ static int run_conv(gr_ctx* ctx, const Layer& L, const float* in, int B, int H, 
                                 (double)(pool ? M / 4 : M) * L.Cout * ((out_raw ? 1 : 0) + (out_act ? 1 : 0) + (res ? 1 : 0)));
     char pname[64];
     if (L.kchunk && bk != 32) return gr_fail(ctx, GR_ESTATE, "conv: chunked layer needs BK = 32");
-    if (precision == GR_PREC_BF16 && L.wbf && L.kchunk == 32 && bn == 160 && !pool && !L.bias && !relu && !gate && H == W &&
-        (H == 32 || H == 16 || H == 8)) {
+    if (precision == GR_PREC_BF16 && L.wbf && L.KH == 3 && L.KW == 3 && L.pad == 1 && (L.stride == 1 || L.stride == 2) && L.Cin % 32 == 0 &&
+        bn == 160 && !pool && !L.bias && !relu && !gate && H == W && (H == 32 || H == 16 || (H == 8 && L.stride == 1))) {
         HaloCcBfParams q;
         q.in = in; q.wgt = L.wbf; q.res = res; q.scale = p.scale; q.shift = p.shift; q.out_raw = out_raw; q.out_act = out_act;
         q.B = B; q.H = H; q.W = W; q.Cin = L.Cin; q.Cout = L.Cout;
-        const int v = bf16_variant(H == 32 ? 0 : H == 16 ? 1 : 2);
-        snprintf(pname, sizeof(pname), "k_conv_halo_cc_bf16<%dx%d,v%d>", H, H, v);
+        const int Hout = H / L.stride;
+        const int v = bf16_variant(Hout == 32 ? 0 : Hout == 16 ? 1 : 2);
+        snprintf(pname, sizeof(pname), "k_conv_halo_cc_bf16<%dx%d%s,v%d>", Hout, Hout, L.stride == 2 ? ",s2" : "", v);
         ProfScope ps_(ctx, pname, st, flops, bytes);
-        //                                         TH  TW NIMG WM TM TN OCC
+        //                                         TH  TW NIMG WM TM TN OCC STRIDE
 #define HCB(...) e = launch_conv_halo_cc_bf16<__VA_ARGS__>(q, st)
-        if (H >= 16) {
+        if (L.stride == 2) {
+            if (Hout == 16) HCB( 8, 16, 1,  4, 1, 5, 1, 2);      // 1 wave per SIMD: the slice prefetch of the 17x33 region needs the registers
+            else            HCB( 8,  8, 2,  4, 1, 5, 1, 2);
+        } else if (H >= 16) {
             switch (v) {
             case 0: HCB( 8, 16, 1,  4, 1, 5, 2); break;
             case 1: HCB(16, 16, 1,  4, 2, 5, 2); break;

@@ -123,8 +123,8 @@ int gr_model_num_classes(const gr_model* m);
  * accumulation; conv1_1 and fc7 stay fp32.  Not bit-exact.  Each layer alone follows its restatement (torch,
  * .bfloat16() operands, wide accumulation) to a median 1e-5 of the largest logit; end to end, activations that land on a
  * bf16 rounding boundary round differently in any two implementations, so logits agree to ~1e-2 of the largest logit --
- * the same order as bf16 against fp32 itself (tests/test_gpu_bf16.py has the numbers).  WideResNet: the stride-1 3x3
- * convs with Cout % 160 == 0 (91 % of WRN-34-10's flops) run in bf16, the rest stays fp32; GR_EINVAL for a net without
+ * the same order as bf16 against fp32 itself (tests/test_gpu_bf16.py has the numbers).  WideResNet: the 3x3 convs (stride 1
+ * and 2) with Cin % 32 == 0, Cout % 160 == 0 (95 % of WRN-34-10's flops) run in bf16, the rest stays fp32; GR_EINVAL for a net without
  * such a layer. */
 #define GR_PREC_F32 0
 #define GR_PREC_BF16 1
