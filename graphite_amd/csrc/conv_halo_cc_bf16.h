@@ -16,13 +16,13 @@
 #include "conv_halo_bf16.h"
 
 struct HaloCcBfParams {
-    const float* in;        // [B,H,W,Cin] f32 NHWC
+    const void* in;         // [B,H,W,Cin] NHWC, f32 or bf16 (IN_BF)
     const uint16_t* wgt;    // bf16, [K/16][Cout/32][2][32][8], k = (chunk, tap, ci%32)
     const float* res;       // [B,H/stride,W/stride,Cout] or null
     const float* scale;     // [Cout] folded BN of the consumer, or null
     const float* shift;
     float* out_raw;         // [B,H,W,Cout] or null
-    float* out_act;         // [B,H,W,Cout] or null
+    void* out_act;          // [B,H/stride,W/stride,Cout] or null; f32 or bf16 (ACT_BF)
     int B, H, W, Cin, Cout; // H, W: input size
 };
 
@@ -47,7 +47,7 @@ struct HaloCcBfGeom {
 };
 
 // WM wavefronts x TM 32-pixel m-tiles cover the NIMG x TH x TW pixels; every wavefront holds TN n-tiles (N = TN*32).
-template <int TH, int TW, int NIMG, int WM, int TM, int TN, int OCC, int STRIDE>
+template <int TH, int TW, int NIMG, int WM, int TM, int TN, int OCC, int STRIDE, bool IN_BF, bool ACT_BF>
 __global__ __launch_bounds__(WM * 64, OCC) void k_conv_halo_cc_bf16(HaloCcBfParams p) {
     using G = HaloCcBfGeom<TH, TW, NIMG, STRIDE>;
     constexpr int CC = 32, NT = WM * 64;
@@ -57,8 +57,9 @@ __global__ __launch_bounds__(WM * 64, OCC) void k_conv_halo_cc_bf16(HaloCcBfPara
     constexpr int SV = STAGE_B / 16, TV = TN * 64;       // vectors per stage / per k-block
     constexpr int VPT = (SV + NT - 1) / NT;
     constexpr int MT = NIMG * TH * TW / 32;
-    constexpr int SEG = CC / 4, NPX = NIMG * THH * TWH, PSTEP = NT / SEG;
-    constexpr int AIT = (NPX + PSTEP - 1) / PSTEP;       // float4 loads per thread and chunk slice
+    constexpr int EPS = IN_BF ? 8 : 4;                   // channels per 16-byte global segment
+    constexpr int SEG = CC / EPS, NPX = NIMG * THH * TWH, PSTEP = NT / SEG;
+    constexpr int AIT = (NPX + PSTEP - 1) / PSTEP;       // 16-byte loads per thread and chunk slice
     static_assert(MT == WM * TM, "m tiling");
     static_assert(PSTEP / TWH + 1 <= THH, "tile too small for the incremental walk");
 
@@ -111,19 +112,19 @@ __global__ __launch_bounds__(WM * 64, OCC) void k_conv_halo_cc_bf16(HaloCcBfPara
     };
 
     // ---- A slice: thread = (4-channel segment, pixel walking the tile in steps of NT/SEG) ----
-    typedef float f32x4 __attribute__((ext_vector_type(4)));
-    f32x4 areg[AIT];
+    u32x4 areg[AIT];
     const int seg = tid % SEG, px0 = tid / SEG;
     auto aload = [&](int ch) {
         if (ch >= nchunk) ch = nchunk - 1;
-        const float* src = p.in + ch * CC + seg * 4;
+        const u32x4* src = reinterpret_cast<const u32x4*>(p.in) + (ch * CC) / EPS + seg;
+        const int cvec = p.Cin / EPS;                     // 16-byte vectors per pixel
         int px = px0, hx = px0 % TWH, hy = (px0 / TWH) % THH, im = px0 / (TWH * THH);
 #pragma unroll
         for (int u = 0; u < AIT; u++) {
             const int gy = STRIDE * y0 + hy - 1, gx = STRIDE * x0 + hx - 1, gb = b0 + im;
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            u32x4 v = {0u, 0u, 0u, 0u};
             if (px < NPX && gb < p.B && (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W)
-                v = *reinterpret_cast<const f32x4*>(src + (((size_t)gb * p.H + gy) * p.W + gx) * p.Cin);
+                v = src[(((size_t)gb * p.H + gy) * p.W + gx) * cvec];
             areg[u] = v;
             px += PSTEP; hx += PSTEP % TWH; hy += PSTEP / TWH;
             if (hx >= TWH) { hx -= TWH; hy++; }
@@ -135,11 +136,17 @@ __global__ __launch_bounds__(WM * 64, OCC) void k_conv_halo_cc_bf16(HaloCcBfPara
 #pragma unroll
         for (int u = 0; u < AIT; u++) {
             if (px < NPX) {
-                bf16x4 h;
-                h[0] = (__bf16)areg[u][0]; h[1] = (__bf16)areg[u][1]; h[2] = (__bf16)areg[u][2]; h[3] = (__bf16)areg[u][3];
                 const int off = STRIDE == 1 ? hy * RSB + hx * PSB
                                             : ((hy & 1) * 2 + (hx & 1)) * PLB + (hy >> 1) * RSB + (hx >> 1) * PSB;
-                *reinterpret_cast<bf16x4*>(asm_ + im * IMGB + off + seg * 8) = h;
+                unsigned char* d = asm_ + im * IMGB + off + seg * (EPS * 2);
+                if constexpr (IN_BF) {
+                    *reinterpret_cast<u32x4*>(d) = areg[u];
+                } else {
+                    const f32x4v f = __builtin_bit_cast(f32x4v, areg[u]);    // whole vector (conv_halo_bf16.h)
+                    bf16x4 h;
+                    h[0] = (__bf16)f[0]; h[1] = (__bf16)f[1]; h[2] = (__bf16)f[2]; h[3] = (__bf16)f[3];
+                    *reinterpret_cast<bf16x4*>(d) = h;
+                }
             }
             px += PSTEP; hx += PSTEP % TWH; hy += PSTEP / TWH;
             if (hx >= TWH) { hx -= TWH; hy++; }
@@ -226,20 +233,22 @@ __global__ __launch_bounds__(WM * 64, OCC) void k_conv_halo_cc_bf16(HaloCcBfPara
                 if (p.out_raw) p.out_raw[row + co] = v;
                 if (p.out_act) {
                     float w = fmaf(v, sc, sh);
-                    p.out_act[row + co] = w > 0.f ? w : 0.f;
+                    w = w > 0.f ? w : 0.f;
+                    if constexpr (ACT_BF) reinterpret_cast<__bf16*>(p.out_act)[row + co] = (__bf16)w;
+                    else reinterpret_cast<float*>(p.out_act)[row + co] = w;
                 }
             }
         }
     }
 }
 
-template <int TH, int TW, int NIMG, int WM, int TM, int TN, int OCC, int STRIDE = 1>
+template <int TH, int TW, int NIMG, int WM, int TM, int TN, int OCC, int STRIDE = 1, bool IN_BF = false, bool ACT_BF = false>
 static inline hipError_t launch_conv_halo_cc_bf16(const HaloCcBfParams& p, hipStream_t st) {
     using G = HaloCcBfGeom<TH, TW, NIMG, STRIDE>;
     constexpr size_t smem = G::A_BYTES + 2 * (size_t)(2 * TN * 1024);
     static_assert(smem <= 160 * 1024, "LDS");
     if (p.H % (TH * STRIDE) || p.W % (TW * STRIDE) || p.Cin % 32 || p.Cout % (TN * 32) || (p.out_act && !(p.scale && p.shift))) return hipErrorInvalidValue;
-    auto kern = k_conv_halo_cc_bf16<TH, TW, NIMG, WM, TM, TN, OCC, STRIDE>;
+    auto kern = k_conv_halo_cc_bf16<TH, TW, NIMG, WM, TM, TN, OCC, STRIDE, IN_BF, ACT_BF>;
     static bool attr_set[64] = {false};                  // the attribute is per device
     int dev_ = 0;
     if (hipGetDevice(&dev_) != hipSuccess || dev_ < 0 || dev_ >= 64) return hipErrorInvalidDevice;

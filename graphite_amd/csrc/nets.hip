@@ -429,9 +429,16 @@ static bool use_igemm_convs();
 static int halo_variant(int layer);
 static int bf16_variant(int layer);
 
+// does this WideResNet conv launch go to conv_halo_cc_bf16.h in the bf16 mode?
+static bool cc_bf16_ok(const Layer& L, int H, int precision) {
+    return precision == GR_PREC_BF16 && L.wbf && L.KH == 3 && L.KW == 3 && L.pad == 1 && (L.stride == 1 || L.stride == 2) &&
+           L.Cin % 32 == 0 && L.Cout % 160 == 0 && !L.bias && (H == 32 || H == 16 || (H == 8 && L.stride == 1));
+}
+
+// in_bf / act_bf (bf16 kernel only): `in` holds bf16, `out_act` is written as bf16
 static int run_conv(gr_ctx* ctx, const Layer& L, const float* in, int B, int H, int W, const float* res, const BnDev* act,
                     float* out_raw, float* out_act, bool relu, bool pool, hipStream_t st, const float* gate = nullptr,
-                    int precision = GR_PREC_F32) {
+                    int precision = GR_PREC_F32, bool in_bf = false, bool act_bf = false) {
     ConvParams p;
     p.in = in; p.wgt = L.w; p.bias = L.bias; p.res = res; p.gate = gate;
     p.scale = act ? act->scale : nullptr; p.shift = act ? act->shift : nullptr;
@@ -459,38 +466,31 @@ static int run_conv(gr_ctx* ctx, const Layer& L, const float* in, int B, int H, 
                                 (double)(pool ? M / 4 : M) * L.Cout * ((out_raw ? 1 : 0) + (out_act ? 1 : 0) + (res ? 1 : 0)));
     char pname[64];
     if (L.kchunk && bk != 32) return gr_fail(ctx, GR_ESTATE, "conv: chunked layer needs BK = 32");
-    if (precision == GR_PREC_BF16 && L.wbf && L.KH == 3 && L.KW == 3 && L.pad == 1 && (L.stride == 1 || L.stride == 2) && L.Cin % 32 == 0 &&
-        bn == 160 && !pool && !L.bias && !relu && !gate && H == W && (H == 32 || H == 16 || (H == 8 && L.stride == 1))) {
+    if ((in_bf || act_bf) && !(cc_bf16_ok(L, H, precision) && H == W)) return gr_fail(ctx, GR_ESTATE, "conv: bf16 activations need the bf16 kernel");
+    if (cc_bf16_ok(L, H, precision) && !pool && !relu && !gate && H == W) {
         HaloCcBfParams q;
         q.in = in; q.wgt = L.wbf; q.res = res; q.scale = p.scale; q.shift = p.shift; q.out_raw = out_raw; q.out_act = out_act;
         q.B = B; q.H = H; q.W = W; q.Cin = L.Cin; q.Cout = L.Cout;
         const int Hout = H / L.stride;
-        const int v = bf16_variant(Hout == 32 ? 0 : Hout == 16 ? 1 : 2);
-        snprintf(pname, sizeof(pname), "k_conv_halo_cc_bf16<%dx%d%s,v%d>", Hout, Hout, L.stride == 2 ? ",s2" : "", v);
+        snprintf(pname, sizeof(pname), "k_conv_halo_cc_bf16<%dx%d%s>", Hout, Hout, L.stride == 2 ? ",s2" : "");
         ProfScope ps_(ctx, pname, st, flops, bytes);
-        //                                         TH  TW NIMG WM TM TN OCC STRIDE
-#define HCB(...) e = launch_conv_halo_cc_bf16<__VA_ARGS__>(q, st)
-        if (L.stride == 2) {
-            if (Hout == 16) HCB( 8, 16, 1,  4, 1, 5, 1, 2);      // 1 wave per SIMD: the slice prefetch of the 17x33 region needs the registers
-            else            HCB( 8,  8, 2,  4, 1, 5, 1, 2);
-        } else if (H >= 16) {
-            switch (v) {
-            case 0: HCB( 8, 16, 1,  4, 1, 5, 2); break;
-            case 1: HCB(16, 16, 1,  4, 2, 5, 2); break;
-            case 2: HCB( 8, 16, 1,  4, 1, 5, 3); break;
-            case 3: HCB(16, 16, 1,  8, 1, 5, 2); break;
-            default: return gr_fail(ctx, GR_EINVAL, "conv_halo_cc_bf16: no variant %d", v);
-            }
-        } else {
-            switch (v) {
-            case 0: HCB( 8,  8, 2,  4, 1, 5, 2); break;
-            case 1: HCB( 8,  8, 4,  4, 2, 5, 2); break;
-            case 2: HCB( 8,  8, 2,  4, 1, 5, 3); break;
-            case 3: HCB( 8,  8, 4,  8, 1, 5, 2); break;
-            default: return gr_fail(ctx, GR_EINVAL, "conv_halo_cc_bf16: no variant %d", v);
-            }
-        }
-#undef HCB
+        //   TH TW NIMG WM TM TN OCC STRIDE; the activation dtypes select one of the instantiations of a shape
+#define HCB4(...)                                                                                                  \
+        do {                                                                                                       \
+            if (in_bf && act_bf) e = launch_conv_halo_cc_bf16<__VA_ARGS__, true, true>(q, st);                     \
+            else if (in_bf) e = launch_conv_halo_cc_bf16<__VA_ARGS__, true, false>(q, st);                         \
+            else if (act_bf) e = launch_conv_halo_cc_bf16<__VA_ARGS__, false, true>(q, st);                        \
+            else e = launch_conv_halo_cc_bf16<__VA_ARGS__, false, false>(q, st);                                   \
+        } while (0)
+        if (L.stride == 2) {            // 1 wave per SIMD: the slice prefetch of the 17x33 region needs the registers
+            if (in_bf) return gr_fail(ctx, GR_ESTATE, "conv: the strided bf16 kernel reads f32 activations");
+            if (Hout == 16) { if (act_bf) e = launch_conv_halo_cc_bf16< 8, 16, 1, 4, 1, 5, 1, 2, false, true>(q, st);
+                              else e = launch_conv_halo_cc_bf16< 8, 16, 1, 4, 1, 5, 1, 2, false, false>(q, st); }
+            else            { if (act_bf) e = launch_conv_halo_cc_bf16< 8,  8, 2, 4, 1, 5, 1, 2, false, true>(q, st);
+                              else e = launch_conv_halo_cc_bf16< 8,  8, 2, 4, 1, 5, 1, 2, false, false>(q, st); }
+        } else if (H >= 16) HCB4( 8, 16, 1,  4, 1, 5, 2, 1);
+        else HCB4( 8,  8, 2,  4, 1, 5, 2, 1);
+#undef HCB4
         if (e != hipSuccess) return gr_fail(ctx, GR_EHIP, "conv_halo_cc_bf16 launch (H=%d): %s", H, hipGetErrorString(e));
         return GR_OK;
     }
@@ -813,10 +813,17 @@ static int wrn_forward(gr_ctx* ctx, gr_model* m, const float* x, int N, float* l
     if ((rc = run_conv(ctx, m->wconv1, x4, N, 32, 32, nullptr, &m->blocks[0].bn1, m->blocks[0].has_sc ? nullptr : xr, o,
                        false, false, st))) return rc;
     int H = 32;
+    bool o_bf = false;                       // does `o` currently hold bf16?
     for (size_t bi = 0; bi < nb; bi++) {
         WrnBlock& b = m->blocks[bi];
         int Ho = H / b.stride;
-        if ((rc = run_conv(ctx, b.conv1, o, N, H, H, nullptr, &b.bn2, nullptr, u, false, false, st, nullptr, m->precision))) return rc;
+        // bf16 mode: an activation is STORED as bf16 when the bf16 kernel produces it and only bf16 kernels read it (u:
+        // conv1 -> conv2; o: conv2 -> the next block's conv1, unless that block also feeds o to its f32 1x1 shortcut
+        // or it is the last one, which the average pool reads).  Same values the consumer would round to: the logits
+        // do not change by a bit (model mask bit 7 keeps f32, for the test).
+        const bool abf = m->precision == GR_PREC_BF16 && !(m->bf16_mask & 0x80);
+        const bool u_bf = abf && cc_bf16_ok(b.conv1, H, m->precision) && cc_bf16_ok(b.conv2, Ho, m->precision);
+        if ((rc = run_conv(ctx, b.conv1, o, N, H, H, nullptr, &b.bn2, nullptr, u, false, false, st, nullptr, m->precision, o_bf, u_bf))) return rc;
         const float* res = xr;
         if (b.has_sc) {
             if ((rc = run_conv(ctx, b.sc, o, N, H, H, nullptr, nullptr, s, nullptr, false, false, st))) return rc;
@@ -826,7 +833,10 @@ static int wrn_forward(gr_ctx* ctx, gr_model* m, const float* x, int N, float* l
         const BnDev* nbn = last ? &m->bnf : &m->blocks[bi + 1].bn1;
         bool need_raw = !last && !m->blocks[bi + 1].has_sc;
         // o is free once conv1 and the shortcut have consumed it: the activated output goes there
-        if ((rc = run_conv(ctx, b.conv2, u, N, Ho, Ho, res, nbn, need_raw ? y : nullptr, o, false, false, st, nullptr, m->precision))) return rc;
+        const bool next_o_bf = abf && !last && cc_bf16_ok(b.conv2, Ho, m->precision) && !m->blocks[bi + 1].has_sc &&
+                               m->blocks[bi + 1].stride == 1 && cc_bf16_ok(m->blocks[bi + 1].conv1, Ho, m->precision);
+        if ((rc = run_conv(ctx, b.conv2, u, N, Ho, Ho, res, nbn, need_raw ? y : nullptr, o, false, false, st, nullptr, m->precision, u_bf, next_o_bf))) return rc;
+        o_bf = next_o_bf;
         if (need_raw) { float* tmp = xr; xr = y; y = tmp; }
         H = Ho;
     }

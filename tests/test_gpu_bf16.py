@@ -172,3 +172,24 @@ def test_bf16_wideresnet_ragged_batch_and_small_net():
         x = torch.rand(n, 3, 32, 32, generator=g)
         e = _per_image_err(model.forward(x).cpu(), W.forward(tsd, x, 10, 10, bf16=True))
         assert float(e[-1]) <= MODE_MAX
+
+
+def test_bf16_wideresnet_bf16_activations_do_not_change_a_logit():
+    """WRN-16-10 (two blocks per stage: every combination of f32 / bf16 activation hand-over occurs).  Default: u and o
+    are stored as bf16 wherever only bf16 kernels read them; mask bit 7 keeps them f32.  Bit-identical logits, and both
+    within the bars of the bf16-operand restatement."""
+    import wrn_torch_reference as W
+    sd = synth.wrn_state_dict(depth=16, widen=10)
+    model = models.WideResNet(depth=16, widen_factor=10).load_state_dict(sd).set_precision("bf16")
+    tsd = {k: torch.as_tensor(v) for k, v in sd.items()}
+    g = torch.Generator().manual_seed(9)
+    for n in (2, 11):
+        x = torch.rand(n, 3, 32, 32, generator=g)
+        a = model.forward(x).cpu()
+        model.hip_model.set_bf16_layers(0xff)
+        b = model.forward(x).cpu()
+        model.hip_model.set_bf16_layers(0x7f)
+        assert torch.equal(a, b)
+        e = _per_image_err(a, W.forward(tsd, x, 16, 10, bf16=True))
+        print(f"WRN-16-10 bf16 n={n}: median {float(e[len(e) // 2]):.2e} max {float(e[-1]):.2e}")
+        assert float(e[-1]) <= MODE_MAX
