@@ -3,19 +3,22 @@
 //
 // Same data movement idea as conv_halo.h -- the haloed input tile is staged in LDS once per workgroup -- with the
 // operands shaped for v_mfma_f32_32x32x16_bf16 (8 k-values per lane, one ds_read_b128 each):
-//   * A: the tile is converted f32 -> bf16 (round to nearest even) while it is staged (or copied, when the producing
-//     layer already stored bf16: IN_BF / OUT_BF -- the values are the same, only the HBM traffic halves); pixel stride CIN*2+16 bytes
-//     (an odd number of 16-byte slots) and a row stride chosen so that the 16-lane groups of ds_read_b128 hit 16
-//     distinct slots for every pixel order used here (linear 16- and 8-wide tiles, 2x2 pool windows).
+//   * A: the tile is converted f32 -> bf16 (round to nearest even) while it is staged, or copied when the producing
+//     layer already stored bf16 (IN_BF / OUT_BF: the values are the same, only the HBM traffic halves); pixel stride
+//     CIN*2+16 bytes (an odd number of 16-byte slots) and a row stride chosen so that the 16-lane groups of
+//     ds_read_b128 hit 16 distinct slots for every pixel order used here (linear 16- and 8-wide tiles, 2x2 pool
+//     windows).  The staging registers are native ext_vector_type vectors: arrays of HIP's uint4 / float4 structs
+//     ended up in scratch memory or cost 60 registers here.
 //   * B: weights are packed at load as [k-block of 16][32-wide n tile][k half][cout][8 k] bf16, i.e. in the exact
 //     order the lanes read them, and streamed global -> registers -> LDS in stages of KBS k-blocks: two LDS buffers,
-//     one workgroup barrier per stage, and a register ring PF stages deep -- a stage is only 0.2-0.5 us of MFMA work,
-//     well under the L2 latency, so the loads of stage s+PF+1 are issued while stage s is computed (an MFMA here is 16x
+//     one workgroup barrier per stage, and a register ring of PF+1 stages -- a stage is only 0.2-0.5 us of MFMA work,
+//     well under the L2 latency, so the loads of stage s+PF+2 are issued while stage s is computed (an MFMA here is 16x
 //     faster than the fp32 one, so the weights can no longer come straight from L2 into every wave's registers).
 //     The stream reads stage indices clamped to the last stage instead of branching (conv_halo.h: a conditional
 //     prefetch costs a full vmcnt drain).
 //   * k order: (tap = ky*5+kx, ci); accumulation order inside an MFMA is the hardware's.
-//   * Epilogue as conv_halo.h: + bias, ReLU, optional 2x2 max-pool in registers, f32 NHWC store.
+//   * Epilogue as conv_halo.h: + bias, ReLU, optional 2x2 max-pool in registers, f32 (or bf16) NHWC store.
+//   * __launch_bounds__ asks for the waves per SIMD that the LDS footprint admits (at most 4).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
