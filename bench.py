@@ -212,6 +212,24 @@ def extras(_hip, engine, models, synth):
         "final_mask_pixels": int(r["pixels"]), "transform_robustness": float(r["transform_robustness"]),
         "note": "stop sign 14 -> pedestrians 27, -m 100 -b 100, binary coarse reduction, seed 42; seeded GTSRBNet with a fitted "
                 "3-sign read-out (the authors' checkpoint is unavailable; reference: ~10 min on an RTX 3080, README.md:26)"}
+    # the same attack with the classifier in the bf16 throughput mode (decisions may differ from fp32: reported, not asserted)
+    try:
+        model.set_precision("bf16")
+        np.random.seed(42); torch.manual_seed(42); random.seed(42)
+        t0 = time.perf_counter()
+        with contextlib.redirect_stdout(io.StringIO()):
+            r16 = gmain.attack_network(
+                model, os.path.join(INP, "GTSRB/images/14.png"), os.path.join(INP, "GTSRB/images/27.png"),
+                os.path.join(INP, "GTSRB/Hulls/14.png"), 14, 27, os.path.join(INP, "GTSRB/Points/14.csv"), "score.py", "Target",
+                a.coarse_error, a.reduce_error, 1, 100, 100, model_type='GTSRB', args=a, write_outputs=False)
+        torch.cuda.synchronize()
+        dt16 = time.perf_counter() - t0
+        res["config2_gtsrb_attack_bf16_mode"] = {
+            "wall_clock_s": dt16, "queries": int(r16["queries"]), "final_mask_pixels": int(r16["pixels"]),
+            "transform_robustness": float(r16["transform_robustness"]), "speedup_vs_f32": dt / dt16,
+            "same_trajectory_as_f32": bool(int(r16["queries"]) == int(r["queries"]) and int(r16["pixels"]) == int(r["pixels"]))}
+    except Exception as e:      # noqa: BLE001
+        res["config2_gtsrb_attack_bf16_mode"] = {"error": "%s: %s" % (type(e).__name__, e)}
     return res
 
 
