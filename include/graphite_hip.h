@@ -144,7 +144,8 @@ int gr_model_predict(gr_ctx* ctx, gr_model* m, const float* x, int N, int64_t* p
  * logits = model(x); loss = CrossEntropyLoss(logits, target); grad = autograd.grad(loss, x)), GTSRBNet only:
  * grad_x [N,3,32,32] dev = d CE(logits_n, target) / d x_n PER IMAGE (no averaging over N); logits [N,43] dev optional.
  * Forward with every activation kept (GTSRBNet.py:35-52), then the transposed layers on the same MFMA kernels
- * (flipped 5x5 taps, W^T), ReLU / max-pool routing as torch's autograd does (first maximum of a window). */
+ * (flipped 5x5 taps, W^T), ReLU / max-pool routing as torch's autograd does (first maximum of a window).
+ * Always fp32, whatever gr_model_set_precision says. */
 int gr_model_input_grad(gr_ctx* ctx, gr_model* m, const float* x, int N, int target, float* logits, float* grad_x,
                         void* stream);
 
