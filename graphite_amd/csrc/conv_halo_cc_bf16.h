@@ -9,7 +9,8 @@
 //   * B: bf16 weights in fragment order [k-block][Cout/32][2][32][8]; one stage = one tap (2 k-blocks x 5 n-tiles =
 //     10 KB), two LDS buffers, one barrier per stage, register ring three stages deep (9 taps per chunk keep the ring
 //     slot of a tap compile-time).  Stage indices are clamped, never branched on.
-//   * Epilogue as conv_halo_cc.h: + residual, raw store, relu(v*scale+shift) store (folded BN of the consumer), f32.
+//   * Epilogue as conv_halo_cc.h (+ residual, raw store, relu(v*scale+shift) store = folded BN of the consumer), but
+//     transposed through LDS so that every global access is 16 bytes.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -213,29 +214,61 @@ __global__ __launch_bounds__(WM * 64, OCC) void k_conv_halo_cc_bf16(HaloCcBfPara
         __syncthreads();
     }
 
-    // ---- epilogue (conv_halo_cc.h, scalar columns) ----
+    // ---- epilogue: + residual, raw store, relu(v*scale+shift) store ----
+    // An accumulator tile has its 32 output channels on the lanes and its 32 pixels in the registers, so storing it
+    // directly takes one 4-byte access per value: 3 x 80 scalar loads / stores per lane here, as much time as ~60 of the
+    // 45-180 weight stages.  Each 32x32 tile therefore goes through a wave-private 4.5 KB LDS patch (the loop's last
+    // barrier has retired every read of the slice and the weight buffers) and comes back with 4 consecutive channels
+    // of one pixel per lane: 16-byte accesses, a quarter of the instructions.
+    {
+        constexpr int EROW = 144;                        // bytes per pixel row of the patch: 9 slots, odd
+        static_assert(NT / 64 * 32 * EROW <= G::A_BYTES + 2 * STAGE_B, "epilogue patches must fit the kernel's LDS");
+        unsigned char* patch = smem_cb + wave * (32 * EROW);
+        const int c4 = lane & 7, prow = lane >> 3;       // read side: channels 4*c4 .. +3 of pixel rows prow + 8*it
+        typedef float f32x4e __attribute__((ext_vector_type(4)));
 #pragma unroll
-    for (int j = 0; j < TN; j++) {
-        const int co = n0 + j * 32 + lp;
-        const float sc = p.out_act ? p.scale[co] : 0.f;
-        const float sh = p.out_act ? p.shift[co] : 0.f;
+        for (int j = 0; j < TN; j++) {
+            const int co4 = n0 + j * 32 + c4 * 4;
+            f32x4e sc = {0.f, 0.f, 0.f, 0.f}, sh = {0.f, 0.f, 0.f, 0.f};
+            if (p.out_act) {
+                sc = *reinterpret_cast<const f32x4e*>(p.scale + co4);
+                sh = *reinterpret_cast<const f32x4e*>(p.shift + co4);
+            }
 #pragma unroll
-        for (int i = 0; i < TM; i++) {
+            for (int i = 0; i < TM; i++) {
 #pragma unroll
-            for (int r = 0; r < 16; r++) {
-                const int l = (wave * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                const int im = l / (TH * TW), q = l % (TH * TW);
-                const int gy = y0 + q / TW, gx = x0 + q % TW, gb = b0 + im;
-                if (gb >= p.B) continue;
-                const size_t row = (((size_t)gb * Ho + gy) * Wo + gx) * p.Cout;
-                float v = acc[i][j][r];
-                if (p.res) v = v + p.res[row + co];
-                if (p.out_raw) p.out_raw[row + co] = v;
-                if (p.out_act) {
-                    float w = fmaf(v, sc, sh);
-                    w = w > 0.f ? w : 0.f;
-                    if constexpr (ACT_BF) reinterpret_cast<__bf16*>(p.out_act)[row + co] = (__bf16)w;
-                    else reinterpret_cast<float*>(p.out_act)[row + co] = w;
+                for (int r = 0; r < 16; r++)
+                    *reinterpret_cast<float*>(patch + ((r & 3) + 8 * (r >> 2) + 4 * lh) * EROW + lp * 4) = acc[i][j][r];
+                // the patch is private to this wavefront and its LDS operations execute in order: only the compiler has to
+                // be kept from moving the reads above the writes (and the next tile's writes above these reads)
+                asm volatile("" ::: "memory");
+                f32x4e pv[4];
+#pragma unroll
+                for (int it = 0; it < 4; it++) pv[it] = *reinterpret_cast<const f32x4e*>(patch + (prow + 8 * it) * EROW + c4 * 16);
+                asm volatile("" ::: "memory");
+#pragma unroll
+                for (int it = 0; it < 4; it++) {
+                    const int rowi = prow + 8 * it;
+                    f32x4e v = pv[it];
+                    const int l = (wave * TM + i) * 32 + rowi;
+                    const int im = l / (TH * TW), q = l % (TH * TW);
+                    const int gy = y0 + q / TW, gx = x0 + q % TW, gb = b0 + im;
+                    if (gb >= p.B) continue;
+                    const size_t off = (((size_t)gb * Ho + gy) * Wo + gx) * p.Cout + co4;
+                    if (p.res) v = v + *reinterpret_cast<const f32x4e*>(p.res + off);
+                    if (p.out_raw) *reinterpret_cast<f32x4e*>(p.out_raw + off) = v;
+                    if (p.out_act) {
+                        f32x4e w;
+#pragma unroll
+                        for (int e = 0; e < 4; e++) { const float t = fmaf(v[e], sc[e], sh[e]); w[e] = t > 0.f ? t : 0.f; }
+                        if constexpr (ACT_BF) {
+                            bf16x4 h;
+                            h[0] = (__bf16)w[0]; h[1] = (__bf16)w[1]; h[2] = (__bf16)w[2]; h[3] = (__bf16)w[3];
+                            *reinterpret_cast<bf16x4*>(reinterpret_cast<__bf16*>(p.out_act) + off) = h;
+                        } else {
+                            *reinterpret_cast<f32x4e*>(reinterpret_cast<float*>(p.out_act) + off) = w;
+                        }
+                    }
                 }
             }
         }
