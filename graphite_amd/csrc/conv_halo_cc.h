@@ -261,22 +261,52 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void k_conv_halo_cc(HaloCcParams p)
             }
         }
     }
+    // Scalar-column tiles (all of them unless VEC): an accumulator tile has its 32 channels on the lanes and its 32
+    // pixels in the registers, so a direct store is one 4-byte access per value -- 3 x 16 x TM x TN scalar loads /
+    // stores per lane.  Each tile goes through a wave-private LDS patch instead (the barrier below retires every read
+    // of the slice) and comes back with 4 consecutive channels of one pixel per lane: 16-byte accesses, a quarter of
+    // the instructions; the arithmetic per value is unchanged (finish / activate), so the results are bit-identical.
+    if (TN4 < TN) {
+        constexpr int EROW = 36;                          // floats per patch row: 9 16-byte slots, odd
+        static_assert(WM * WN * 32 * EROW <= NIMG * IMGS, "epilogue patches must fit the slice's LDS");
+        __syncthreads();
+        float* patch = smem + wave * (32 * EROW);
+        const int c4 = lane & 7, prow = lane >> 3;
 #pragma unroll
-    for (int j = TN4; j < TN; j++) {
-        const int co = n0 + (wn * TN + j) * 32 + lp;
-        if (co >= p.Cout) continue;
-        const float bi = p.bias ? p.bias[co] : 0.f;
-        const float sc = p.out_act ? p.scale[co] : 0.f;
-        const float sh = p.out_act ? p.shift[co] : 0.f;
+        for (int j = TN4; j < TN; j++) {
+            const int co4 = n0 + (wn * TN + j) * 32 + c4 * 4;
+            const bool cok = co4 < p.Cout;                // Cout % 4 == 0 (checked at launch)
+            const float4 bi = (p.bias && cok) ? *reinterpret_cast<const float4*>(p.bias + co4) : z4;
+            const float4 sc = (p.out_act && cok) ? *reinterpret_cast<const float4*>(p.scale + co4) : z4;
+            const float4 sh = (p.out_act && cok) ? *reinterpret_cast<const float4*>(p.shift + co4) : z4;
 #pragma unroll
-        for (int i = 0; i < TM; i++) {
+            for (int i = 0; i < TM; i++) {
 #pragma unroll
-            for (int r = 0; r < 16; r++) {
-                size_t row;
-                if (!out_row(wm * TM + i, r, &row)) continue;
-                const float v = finish(acc[i][j][r], p.res ? p.res[row + co] : 0.f, bi);
-                if (p.out_raw) p.out_raw[row + co] = v;
-                if (p.out_act) p.out_act[row + co] = activate(v, sc, sh);
+                for (int r = 0; r < 16; r++) patch[((r & 3) + 8 * (r >> 2) + 4 * lh) * EROW + lp] = acc[i][j][r];
+                asm volatile("" ::: "memory");            // wave-private, LDS operations of a wave execute in order
+                float4 pv[4];
+#pragma unroll
+                for (int it = 0; it < 4; it++) pv[it] = *reinterpret_cast<const float4*>(patch + (prow + 8 * it) * EROW + c4 * 4);
+                asm volatile("" ::: "memory");
+#pragma unroll
+                for (int it = 0; it < 4; it++) {
+                    const int l = (wm * TM + i) * 32 + prow + 8 * it;
+                    const int im = l / (TH * TW), q = l % (TH * TW);
+                    const int gy = y0 + q / TW, gx = x0 + q % TW, gb = b0 + im;
+                    if (gb >= p.B || !cok) continue;
+                    const size_t row = (((size_t)gb * p.H + gy) * p.W + gx) * p.Cout;
+                    const float4 rs = p.res ? *reinterpret_cast<const float4*>(p.res + row + co4) : z4;
+                    float4 v;
+                    v.x = finish(pv[it].x, rs.x, bi.x); v.y = finish(pv[it].y, rs.y, bi.y);
+                    v.z = finish(pv[it].z, rs.z, bi.z); v.w = finish(pv[it].w, rs.w, bi.w);
+                    if (p.out_raw) *reinterpret_cast<float4*>(p.out_raw + row + co4) = v;
+                    if (p.out_act) {
+                        float4 w;
+                        w.x = activate(v.x, sc.x, sh.x); w.y = activate(v.y, sc.y, sh.y);
+                        w.z = activate(v.z, sc.z, sh.z); w.w = activate(v.w, sc.w, sh.w);
+                        *reinterpret_cast<float4*>(p.out_act + row + co4) = w;
+                    }
+                }
             }
         }
     }
