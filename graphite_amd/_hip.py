@@ -39,6 +39,7 @@ SIGNATURES = {
     "gr_add_noise": (_i, [_vp, _vp, _i, _i, _vp, _vp, _i, _i, _f, _i, _vp, _vp, _vp, _vp]),
     "gr_warp_perspective": (_i, [_vp, _vp, _i, _i, _vp, _i, _i, _vp, _vp]),
     "gr_transform_composited": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp, _i, _i, _vp, _vp]),
+    "gr_transform_composited_static": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp, _i, _i, _vp, _vp]),
     "gr_warp_batch": (_i, [_vp, _vp, _i, _i, _vp, _vp, _i, _i, _i, _vp, _f, _i, _i, _vp, _vp]),
     "gr_model_load_gtsrb": (_i, [_vp, _vp, _vp, _i, C.POINTER(_vp)]),
     "gr_model_load_wrn": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, C.POINTER(_vp)]),
@@ -240,6 +241,16 @@ def transform_composited(img, mask_lg, pert, tab, net, normalize):
     _check(ctx(), load_library().gr_transform_composited(ctx(), _p(i), _p(m), _p(p), H, W, xf._h, int(normalize), net,
                                                          _p(out), _stream()), "gr_transform_composited")
     return out.cpu().numpy()
+
+
+def transform_composited_static(img_d, mask_lg_d, pert_d, xf, out_d, normalize=True, net=32):
+    """gr_transform_composited_static: device tensors in, `out_d` [T,3,net,net] preallocated by the caller; the library
+    allocates nothing (composites live in its 4 MiB static device array)."""
+    _, H, W = img_d.shape
+    _check(ctx(), load_library().gr_transform_composited_static(ctx(), _p(img_d), _p(mask_lg_d), _p(pert_d), H, W, xf._h,
+                                                                int(normalize), net, _p(out_d), _stream()),
+           "gr_transform_composited_static")
+    return out_d
 
 
 def warp_batch_dev(img, masks, thetas, tab, lbd, normalize, net=32):

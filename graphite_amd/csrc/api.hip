@@ -6,6 +6,13 @@
 
 static thread_local std::string g_create_err;
 
+// Scratch of gr_transform_composited_static (the entry point that allocates nothing): the RGBX composites of ONE
+// (img, mask_lg, pert) triple, one per blur kernel in use (<= 4), for frames of at most GR_STATIC_MAX_PIXELS pixels.
+// Every GPU the library runs on holds its own copy until the process ends.  In host code the NAME is only a handle for
+// hipGetSymbolAddress (gr_ctx_create resolves it once per device, with that device current); kernels, memsets and copies
+// take the resolved per-device pointer gr_ctx::static_scratch.
+static __device__ __align__(256) unsigned char scratch[(size_t)4 * GR_STATIC_MAX_PIXELS * 16];
+
 int gr_fail(gr_ctx* ctx, int code, const char* fmt, ...) {
     char buf[512];
     va_list ap;
@@ -111,8 +118,12 @@ extern "C" int gr_ctx_create(int device, gr_ctx** out) {
     if (e != hipSuccess) return gr_fail(nullptr, GR_EHIP, "hipGetDeviceProperties: %s", hipGetErrorString(e));
     if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
         return gr_fail(nullptr, GR_ESTATE, "device %d is %s; this library is built for gfx950 only", device, prop.gcnArchName);
+    void* sp = nullptr;
+    e = hipGetSymbolAddress(&sp, HIP_SYMBOL(scratch));          // this device's copy (hipSetDevice(device) above)
+    if (e != hipSuccess || !sp) return gr_fail(nullptr, GR_EHIP, "hipGetSymbolAddress(scratch): %s", hipGetErrorString(e));
     gr_ctx* c = new gr_ctx();
     c->device = device;
+    c->static_scratch = (char*)sp;
     *out = c;
     return GR_OK;
 }
@@ -251,6 +262,24 @@ extern "C" int gr_transform_composited(gr_ctx* ctx, const float* img, const floa
     size_t att_bytes = gr_align((size_t)xf->nslots * H * W * 16);
     if ((rc = gr_ws_reserve(ctx, att_bytes, stream))) return rc;
     float* att = (float*)ctx->ws;
+    if ((rc = px_composite_from_pert(ctx, img, mask_lg, pert, H, W, xf, att, st))) return rc;
+    return px_warp_net(ctx, att, H, W, xf, 0, xf->T, 0, normalize, net, out, st);
+}
+
+// gr_transform_composited without any allocation: the composites live in this device's copy of `scratch`.
+extern "C" int gr_transform_composited_static(gr_ctx* ctx, const float* img, const float* mask_lg, const float* pert, int H,
+                                              int W, const gr_xforms* xf, int normalize, int net, float* out, void* stream) {
+    NEED_CTX();
+    if (!img || !mask_lg || !pert || !out) return gr_fail(ctx, GR_EINVAL, "gr_transform_composited_static: null pointer");
+    int rc = check_frame(ctx, H, W, H, W, net, xf);
+    if (rc) return rc;
+    if ((long long)H * W > GR_STATIC_MAX_PIXELS)
+        return gr_fail(ctx, GR_EINVAL, "gr_transform_composited_static: frame %dx%d exceeds the static scratch (at most %d pixels)",
+                       H, W, GR_STATIC_MAX_PIXELS);
+    if (ctx->prof) return gr_fail(ctx, GR_ESTATE, "gr_transform_composited_static: profiling creates HIP events; turn it off");
+    if (!ctx->static_scratch) return gr_fail(ctx, GR_ESTATE, "static scratch not resolved");
+    hipStream_t st = (hipStream_t)stream;
+    float* att = (float*)ctx->static_scratch;             // every composite texel the warp reads is rewritten: no clearing
     if ((rc = px_composite_from_pert(ctx, img, mask_lg, pert, H, W, xf, att, st))) return rc;
     return px_warp_net(ctx, att, H, W, xf, 0, xf->T, 0, normalize, net, out, st);
 }

@@ -100,6 +100,17 @@ int gr_warp_perspective(gr_ctx* ctx, const float* src, int H, int W, const doubl
  * (img, mask_lg, pert as returned by add_noise).  out = [T,3,net,net]. */
 int gr_transform_composited(gr_ctx* ctx, const float* img, const float* mask_lg, const float* pert, int H, int W,
                             const gr_xforms* xf, int normalize, int net, float* out, void* stream);
+/* gr_transform_composited for callers that cannot allocate device memory (code under HIP graph capture, tight serving
+ * loops, harnesses that forbid hipMalloc).  No counterpart in the reference.  Same arguments, same results bit for bit;
+ * the composites (one RGBX f32 image per blur kernel in use, <= 4) are kept in a file-scope __device__ array of
+ * 4 * GR_STATIC_MAX_PIXELS * 16 bytes (4 MiB) that every GPU the library runs on holds until the process ends, instead of
+ * the growable workspace: the call makes no hipMalloc / hipFree and creates no events.  GR_EINVAL when H*W exceeds
+ * GR_STATIC_MAX_PIXELS (244x244 GTSRB frames fit); GR_ESTATE while gr_profile_enable is on.  All calls on one GPU share
+ * that array: calls that overlap on one GPU (two streams, two contexts on the same device) race.  Nothing in it has to
+ * start at zero -- every texel a call reads it has written first. */
+#define GR_STATIC_MAX_PIXELS 65536
+int gr_transform_composited_static(gr_ctx* ctx, const float* img, const float* mask_lg, const float* pert, int H, int W,
+                                   const gr_xforms* xf, int normalize, int net, float* out, void* stream);
 /* get_transformed_images, transforms.py:162-173, for C candidates x T transforms in one pass:
  * masks/thetas = [C,3,nh,nw]; out = [C,T,3,net,net]. */
 int gr_warp_batch(gr_ctx* ctx, const float* img, int H, int W, const float* masks, const float* thetas, int C,
