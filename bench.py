@@ -2,15 +2,17 @@
 """Benchmark of the transform-robustness scoring path (BASELINE.json metric: transformed images
 classified / s, whole job).
 
-    python bench.py --gpus N --steps K --warmup W        (N>1: launched by torch.distributed.run)
+    python bench.py --gpus N --steps K --warmup W
 
-Workload (sharded): per GPU 512 mask candidates x 1000 seed-42 GTSRB transforms
-of the stop-sign victim (14.png, hull 14, Points/14.csv), classified by GTSRBNet in fp32 with
-seeded synthetic weights (the reference's checkpoint is not available).  N GPUs evaluate 512*N
-candidates (weak scaling): the flattened (candidate x transform) index space is split evenly over
-the ranks, each rank calls gr_tr_hits on its slice, and the int32[C] hit counts are summed by one
-all-reduce (RCCL).  A "step" is one full evaluation of all candidates; inputs are resident in HBM
-before the timed region.
+N > 1 either under torch.distributed.run (one rank per GPU, RANK / LOCAL_RANK / WORLD_SIZE from the environment) or
+by itself: without WORLD_SIZE the parent starts the N ranks before touching the GPU (spawn_ranks).
+
+Workload = BASELINE config 4, literally: 4096 mask candidates x 1000 seed-42 GTSRB transforms of the stop-sign victim
+(14.png, hull 14, Points/14.csv), classified by GTSRBNet in fp32 with seeded synthetic weights (the reference's
+checkpoint is not available).  The job is FIXED (strong scaling): the flattened (candidate x transform) index space is
+split evenly over the ranks, each rank calls gr_tr_hits on its slice, and the int32[C] hit counts are summed by one
+all-reduce (RCCL).  A "step" is one full evaluation of all 4,096,000 images; inputs are resident in HBM before the
+timed region.  `--cands-per-gpu K` gives the weak-scaling variant (K candidates per GPU).
 
 Besides the contract fields the JSON line carries
   roofline      the dominant kernel (an fp32 MFMA implicit-GEMM conv instantiation): algorithmic
@@ -233,27 +235,90 @@ def extras(_hip, engine, models, synth):
     return res
 
 
+def spawn_ranks(n, argv):
+    """`python bench.py --gpus N` without a launcher: the parent starts N worker processes (one rank per GPU, the
+    environment torch.distributed.run would give them) BEFORE anything in it touches the GPU, waits for all of them and
+    relays rank 0's JSON line.  A failed worker ends the others and the run exits non-zero.  With fewer than N GPUs
+    visible (the 1-GPU development box) the ranks share device 0 and use gloo: a rehearsal of the sharding logic, not a
+    scaling measurement -- the line says so."""
+    import signal
+    import socket
+    import subprocess
+    ndev = torch.cuda.device_count()                    # does not initialise the GPU
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), LOCAL_WORLD_SIZE=str(n))
+        if ndev < n:
+            env["GRAPHITE_BENCH_ONE_DEVICE"] = "1"
+            env["GRAPHITE_BENCH_BACKEND"] = "gloo"
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    failed = None
+    pending = set(range(n))
+    while pending and failed is None:
+        for r in sorted(pending):
+            if r == 0:
+                continue
+            rc = procs[r].poll()
+            if rc is not None:
+                pending.discard(r)
+                if rc != 0:
+                    failed = (r, rc)
+        if 0 in pending:
+            try:
+                out0, _ = procs[0].communicate(timeout=0.5)
+                pending.discard(0)
+                if procs[0].returncode != 0:
+                    failed = (0, procs[0].returncode)
+            except subprocess.TimeoutExpired:
+                pass
+        else:
+            time.sleep(0.2)
+    if failed is not None:
+        for p in procs:
+            if p.poll() is None:
+                p.send_signal(signal.SIGTERM)
+        for p in procs:
+            try:
+                p.wait(timeout=20)
+            except subprocess.TimeoutExpired:
+                p.kill()
+        raise SystemExit("bench.py: rank %d exited with code %d" % failed)
+    sys.stdout.write(out0.decode())
+    sys.stdout.flush()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--cands-per-gpu", type=int, default=512)
+    ap.add_argument("--candidates", type=int, default=4096,
+                    help="TOTAL candidates of the job, split over the ranks (BASELINE config 4: 4096)")
+    ap.add_argument("--cands-per-gpu", type=int, default=0,
+                    help="weak-scaling variant: this many candidates per GPU instead of a fixed total")
     ap.add_argument("--transforms", type=int, default=1000)
-    ap.add_argument("--chunk", type=int, default=32000, help="images per classifier launch (library default 8192); 32000 divides the 512,000-image step into 16 equal launches")
+    ap.add_argument("--chunk", type=int, default=32000, help="images per classifier launch (library default 8192); 32000 divides the 4,096,000-image job evenly for 1/2/4/8 ranks")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="skip the per-kernel HIP-event timing")
     ap.add_argument("--no-extras", action="store_true",
                     help="skip the secondary measurements (config 2 attack wall-clock, config 3 CIFAR WideResNet-34-10)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return spawn_ranks(args.gpus, sys.argv[1:])
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus N>1 must be launched with torch.distributed.run --nproc-per-node N")
-    # Rehearsal knobs for a 1-GPU box (never set by the driver): all ranks on device 0, gloo instead of RCCL.
+        raise SystemExit("--gpus %d does not match WORLD_SIZE=%d" % (args.gpus, world))
+    # Rehearsal knobs for a 1-GPU box (set by spawn_ranks when fewer GPUs than ranks are visible, never by the driver):
+    # all ranks on device 0, gloo instead of RCCL.
     one_device = os.environ.get("GRAPHITE_BENCH_ONE_DEVICE") == "1"
     backend = os.environ.get("GRAPHITE_BENCH_BACKEND", "nccl")
     dev = 0 if one_device else local_rank
@@ -267,7 +332,8 @@ def main():
 
     from graphite_amd import _hip, engine, models, synth
 
-    C_total = args.cands_per_gpu * world
+    weak = args.cands_per_gpu > 0
+    C_total = args.cands_per_gpu * world if weak else args.candidates
     T = args.transforms
     case = bench_case(T)
     hull = case["hull"]
@@ -281,7 +347,7 @@ def main():
     target = 1
 
     def step():
-        return engine.tr_hits(model, img_d, masks_d, thetas_d, xf, target)
+        return engine.tr_hits(model, img_d, masks_d, thetas_d, xf, target, distributed=world > 1)
 
     def fence():
         torch.cuda.synchronize()
@@ -315,12 +381,16 @@ def main():
     out = {
         "metric": "transformed images classified/sec (whole job)",
         "value": value, "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": 1000.0 * dt / max(1, args.steps), "higher_is_better": True, "scaling": "weak",
+        "ms_per_step": 1000.0 * dt / max(1, args.steps), "higher_is_better": True, "scaling": "weak" if weak else "strong",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "config4 sweep shard: %d candidates/GPU x %d transforms, GTSRBNet fp32, stop-sign victim 244x244"
-                               % (args.cands_per_gpu, T),
-                   "candidates_total": C_total, "transforms": T, "chunk_images": args.chunk,
-                   "sharding": "contiguous slices of the (candidate x transform) index, one int32[C] all-reduce"},
+        "config": {"workload": ("config4 sweep, weak-scaling variant: %d candidates/GPU x %d transforms" % (args.cands_per_gpu, T)
+                                if weak else "config4 sweep: %d candidates x %d transforms in total, split over the ranks" % (C_total, T))
+                               + ", GTSRBNet fp32, stop-sign victim 244x244",
+                   "candidates_total": C_total, "transforms": T, "images_per_step": C_total * T, "chunk_images": args.chunk,
+                   "sharding": "contiguous slices of the (candidate x transform) index, one int32[C] all-reduce",
+                   "backend": (backend if world > 1 else None),
+                   "rehearsal_all_ranks_on_one_gpu": bool(one_device and world > 1),
+                   "per_kernel_hip_events_in_timed_region": not args.no_profile},
         "tr_queries_per_s": C_total * args.steps / dt,
         "hits_checksum": int(hits.sum().item()),
     }

@@ -46,6 +46,7 @@ int gr_ws_reserve(gr_ctx* ctx, size_t bytes, void* stream) {
 // ---------------------------------------------------------------------------------------------
 // per-kernel profiling (HIP events on the caller's stream)
 // ---------------------------------------------------------------------------------------------
+static void prof_drain(gr_ctx* c, size_t count);
 static hipEvent_t prof_event(gr_ctx* c) {
     if (!c->prof_pool.empty()) { hipEvent_t e = c->prof_pool.back(); c->prof_pool.pop_back(); return e; }
     hipEvent_t e = nullptr;
@@ -60,6 +61,9 @@ ProfScope::ProfScope(gr_ctx* c, const char* name, hipStream_t s, double flops, d
     c->prof_entries[entry].launches++;
     c->prof_entries[entry].flops += flops;
     c->prof_entries[entry].bytes += bytes;
+    // a long job (config 4: ~1,500 launches per step) must not hold an event pair per launch until the end: read back the
+    // older half, whose kernels finished long ago, while >= 1024 launches are still queued behind them
+    if (c->prof_pending.size() >= 2048) prof_drain(c, 1024);
     e0 = prof_event(c); e1 = prof_event(c);
     if (e0 && e1) (void)hipEventRecord(e0, st);
 }
@@ -68,31 +72,34 @@ ProfScope::~ProfScope() {
     (void)hipEventRecord(e1, st);
     ctx->prof_pending.push_back({entry, e0, e1});
 }
-static void prof_drain(gr_ctx* c) {
-    for (auto& p : c->prof_pending) {
+// Reads back the first `count` pending event pairs (all of them by default) and returns their events to the pool.
+static void prof_drain(gr_ctx* c, size_t count) {
+    if (count > c->prof_pending.size()) count = c->prof_pending.size();
+    for (size_t i = 0; i < count; i++) {
+        ProfPending& p = c->prof_pending[i];
         float ms = 0.f;
         if (hipEventSynchronize(p.e1) == hipSuccess && hipEventElapsedTime(&ms, p.e0, p.e1) == hipSuccess)
             c->prof_entries[p.entry].ms += ms;
         c->prof_pool.push_back(p.e0);
         c->prof_pool.push_back(p.e1);
     }
-    c->prof_pending.clear();
+    c->prof_pending.erase(c->prof_pending.begin(), c->prof_pending.begin() + count);
 }
 extern "C" int gr_profile_enable(gr_ctx* ctx, int on) {
     if (!ctx) return GR_EINVAL;
-    if (!on) prof_drain(ctx);
+    if (!on) prof_drain(ctx, (size_t)-1);
     ctx->prof = on != 0;
     return GR_OK;
 }
 extern "C" int gr_profile_reset(gr_ctx* ctx) {
     if (!ctx) return GR_EINVAL;
-    prof_drain(ctx);
+    prof_drain(ctx, (size_t)-1);
     ctx->prof_entries.clear();
     return GR_OK;
 }
 extern "C" int gr_profile_read(gr_ctx* ctx, int max_entries, gr_prof_entry* out) {
     if (!ctx) return GR_EINVAL;
-    prof_drain(ctx);
+    prof_drain(ctx, (size_t)-1);
     int n = (int)ctx->prof_entries.size();
     if (!out) return n;
     if (n > max_entries) n = max_entries;
@@ -131,7 +138,7 @@ extern "C" int gr_ctx_create(int device, gr_ctx** out) {
 extern "C" void gr_ctx_destroy(gr_ctx* ctx) {
     if (!ctx) return;
     if (ctx->ws) { (void)hipDeviceSynchronize(); (void)hipFree(ctx->ws); }
-    prof_drain(ctx);
+    prof_drain(ctx, (size_t)-1);
     for (hipEvent_t e : ctx->prof_pool) (void)hipEventDestroy(e);
     delete ctx;
 }

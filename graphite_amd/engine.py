@@ -4,9 +4,11 @@
     imgs = get_transformed_images(image, masks[c], transforms, lbd, thetas[c], pt_file, 32, model_type)
     err, n = run_predictions(model, imgs, label, target)         # reference utils.py:60
     hits[c] = round((1 - err) * n)
-but in one pass over C x T images on the GPU; with torch.distributed initialised the flattened
-(candidate x transform) index space is split evenly over the ranks and the per-candidate counts
-are summed with ONE int32[C] all-reduce (RCCL over xGMI on a GPU node, gloo in the CPU tests).
+but in one pass over C x T images on the GPU.  Sharding over ranks is OPT-IN (`distributed=True` or a process
+group): the flattened (candidate x transform) index space is then split evenly over the ranks and the per-candidate
+counts are summed with ONE int32[C] all-reduce (RCCL over xGMI on a GPU node, gloo in the CPU tests).  It is opt-in
+because every rank of the group must make the same call with the same (C, T): a process that merely has a
+torch.distributed group initialised for something else must not find collectives inside boost / generate_mask.
 """
 import numpy as np
 import torch
@@ -37,15 +39,40 @@ def allreduce_hits(hits, group=None):
     return hits
 
 
-def sharded_hits(eval_slice, total, distributed=True, group=None):
-    """Run `eval_slice(begin, count) -> int32[C]` (partial counts of images [begin, begin+count) of the
-    flattened candidate x transform index) on this rank's slice and sum over the ranks."""
+_agreed = set()     # (group id, total, C) shapes already checked across the ranks
+
+
+def _assert_same_work(total, hits, group):
+    """First time a (total, C) shape is sharded on a group: one MAX all-reduce of (total, C, -total, -C) proves that
+    every rank is evaluating the same index space (ranks that disagree would otherwise sum unrelated counts)."""
     import torch.distributed as dist
-    sharded = distributed and dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+    key = (id(group), int(total), int(hits.numel()))
+    if key in _agreed:
+        return
+    v = torch.tensor([total, hits.numel(), -total, -hits.numel()], dtype=torch.int64)
+    if dist.get_backend(group) != "gloo":
+        v = v.to(hits.device)
+    dist.all_reduce(v, op=dist.ReduceOp.MAX, group=group)
+    v = v.cpu().tolist()
+    if not (v[0] == -v[2] == total and v[1] == -v[3] == hits.numel()):
+        raise RuntimeError("sharded tr_hits: ranks disagree on the work (images max %d / min %d, candidates max %d / min %d)"
+                           % (v[0], -v[2], v[1], -v[3]))
+    _agreed.add(key)
+
+
+def sharded_hits(eval_slice, total, distributed=False, group=None):
+    """Run `eval_slice(begin, count) -> int32[C]` (partial counts of images [begin, begin+count) of the
+    flattened candidate x transform index) on this rank's slice and sum over the ranks.  Unsharded unless
+    `distributed` is true (or a group is given) AND torch.distributed is initialised with more than one rank."""
+    import torch.distributed as dist
+    sharded = ((distributed or group is not None) and dist.is_available() and dist.is_initialized()
+               and dist.get_world_size(group) > 1)
     if not sharded:
         return eval_slice(0, total)
     begin, count = shard_range(total, dist.get_rank(group), dist.get_world_size(group))
-    return allreduce_hits(eval_slice(begin, count), group)
+    hits = eval_slice(begin, count)
+    _assert_same_work(total, hits, group)
+    return allreduce_hits(hits, group)
 
 
 def _as_table(transforms, w, h, pt_file):
@@ -57,13 +84,15 @@ def _as_table(transforms, w, h, pt_file):
 
 
 def tr_hits(model, image, masks, thetas, transforms, target, pt_file='inputs/GTSRB/Points/14.csv', lbd=1.0,
-            model_type='GTSRB', distributed=True, return_preds=False):
+            model_type='GTSRB', distributed=False, return_preds=False, group=None):
     """hits[c] = number of the T transformed images of candidate c classified as `target`.
 
     image [3,H,W]; masks, thetas [C,3,h,w] (CPU or CUDA tensors / numpy); transforms = the list from
     get_transform_params, a table from build_xform_table, or a cached _hip.XformTable.
     Returns an int32 CUDA tensor [C] (and int64 predictions [C,T] if return_preds; with sharding
     each rank's predictions cover its own slice, -1 elsewhere).
+    distributed / group: shard over the ranks of torch.distributed's default (or the given) group -- every rank must
+    make this same call; off by default.
     """
     hip_model = getattr(model, "hip_model", model)
     img = _hip.to_dev(image)
@@ -81,7 +110,7 @@ def tr_hits(model, image, masks, thetas, transforms, target, pt_file='inputs/GTS
         keep["preds"] = preds
         return hits
 
-    hits = sharded_hits(eval_slice, total, distributed)
+    hits = sharded_hits(eval_slice, total, distributed, group)
     if return_preds:
         return hits, keep["preds"].view(m.shape[0], xf.T)
     return hits

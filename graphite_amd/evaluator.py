@@ -15,8 +15,12 @@ from .transforms import build_xform_table
 
 
 class TREvaluator:
-    def __init__(self, model, image, transforms, pt_file, model_type='GTSRB', label=None, target=None, lbd=1.0):
+    def __init__(self, model, image, transforms, pt_file, model_type='GTSRB', label=None, target=None, lbd=1.0,
+                 distributed=False, group=None):
+        """distributed / group: shard every evaluation over torch.distributed's ranks (engine.tr_hits); opt-in, and only
+        valid when ALL ranks run the identical seeded driver in lock-step."""
         self.model, self.model_type, self.label, self.target, self.lbd = model, model_type, label, target, float(lbd)
+        self.distributed, self.group = bool(distributed), group
         self.image = image
         self.n = len(transforms)
         self.transforms = transforms
@@ -37,10 +41,10 @@ class TREvaluator:
             from .engine import tr_hits
             if self.target is not None:
                 hits = tr_hits(self.model, self._img_d, masks, thetas, self._xf, self.target, lbd=self.lbd,
-                               model_type=self.model_type).cpu().numpy()
+                               model_type=self.model_type, distributed=self.distributed, group=self.group).cpu().numpy()
                 return [((1.0 - int(h) * 1.0 / N), N) for h in hits]
             same = tr_hits(self.model, self._img_d, masks, thetas, self._xf, self.label, lbd=self.lbd,
-                           model_type=self.model_type).cpu().numpy()
+                           model_type=self.model_type, distributed=self.distributed, group=self.group).cpu().numpy()
             return [((1.0 - (N - int(h)) * 1.0 / N), N) for h in same]          # untargeted: count preds != label
         # duck-typed classifier (anything with .predict): images from the fused warp, labels from the model
         from .transforms import get_transformed_images
@@ -58,7 +62,8 @@ class TREvaluator:
     def swapped(self, image, label, target):
         """Same model / transforms with another base image and labels (the 'Victim' heatmap,
         generate_mask.py:262-263, transforms the TARGET image and counts VICTIM-label hits)."""
-        return TREvaluator(self.model, image, self.transforms, self.pt_file, self.model_type, label, target, self.lbd)
+        return TREvaluator(self.model, image, self.transforms, self.pt_file, self.model_type, label, target, self.lbd,
+                           self.distributed, self.group)
 
     # ---- image helpers (cv2.resize / add_noise in the reference's drivers) ----------------------
     @staticmethod

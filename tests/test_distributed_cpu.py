@@ -34,7 +34,9 @@ def _worker(rank, world, port, C, T, target, q):
         np.add.at(hits, (np.arange(begin, begin + count) // T)[sl == target], 1)
         return torch.from_numpy(hits)
 
-    out = engine.sharded_hits(eval_slice, C * T)
+    out = engine.sharded_hits(eval_slice, C * T, distributed=True)
+    plain = engine.sharded_hits(eval_slice, C * T)           # opt-in: without the flag an initialised group is ignored
+    assert calls.pop() == (0, C * T) and plain.sum() == (preds == target).sum()
     q.put((rank, out.numpy().tolist(), calls))
     dist.barrier()
     dist.destroy_process_group()
@@ -67,6 +69,34 @@ def test_sharded_hits_gloo(world, C, T):
     assert pos == C * T
     sizes = [c for _, c in covered]
     assert max(sizes) - min(sizes) <= 1
+
+
+def _disagree_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    C = 4 + rank                                            # rank 1 believes there is one more candidate
+    try:
+        engine.sharded_hits(lambda b, c: torch.zeros(C, dtype=torch.int32), C * 10, distributed=True)
+        q.put((rank, "no error"))
+    except RuntimeError as e:
+        q.put((rank, str(e)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_ranks_that_disagree_on_the_work_fail_loudly():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_disagree_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(2)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all("ranks disagree" in msg for _, msg in res), res
 
 
 def test_shard_range_properties():
