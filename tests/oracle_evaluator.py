@@ -10,6 +10,7 @@ from graphite_amd.transforms import build_xform_table
 
 class OracleEvaluator:
     def __init__(self, state_dict, image, transforms, pt_file, model_type, label, target, nthreads=16):
+        self.state_dict, self.transforms, self.pt_file, self.model_type = state_dict, transforms, pt_file, model_type
         self.tensors = weights.gtsrb_tensor_list(state_dict)
         self.image = np.ascontiguousarray(image.numpy(), dtype=np.float32)
         self.tab = build_xform_table(transforms, image.shape[2], image.shape[1], pt_file)
@@ -35,7 +36,9 @@ class OracleEvaluator:
         return self.errors([mask], [theta])[0]
 
     def swapped(self, img, label, target):
-        raise NotImplementedError
+        """The 'Victim' heatmap (generate_mask.py:262-263 in the reference): same model / transforms on the TARGET image."""
+        return OracleEvaluator(self.state_dict, img, self.transforms, self.pt_file, self.model_type, label, target,
+                               self.nthreads)
 
     @staticmethod
     def resize(t, h, w):
