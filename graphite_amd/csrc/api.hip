@@ -205,6 +205,8 @@ extern "C" int gr_xforms_create(gr_ctx* ctx, const gr_xform* h, int T, gr_xforms
         d[t].crop_x = h[t].crop_x; d[t].crop_y = h[t].crop_y;
         d[t].slot = slot_of[h[t].blur];
         d[t].bw0 = warp_block_w(h[t].crop_x, h[t].crop_y);
+        d[t].sep = (d[t].Mi[1] == 0.0 && d[t].Mi[7] == 0.0) ? 1 : 0;
+        d[t].pad_ = 0;
         memcpy(d[t].lut, h[t].lut, 256);
     }
     hipError_t e = hipMalloc((void**)&x->dev, sizeof(XformDev) * T);
@@ -397,18 +399,20 @@ extern "C" int gr_tr_hits(gr_ctx* ctx, gr_model* m, const float* img, int H, int
     if (img_count == 0) return GR_OK;
     const int ncls = gr_model_num_classes(m);
     const int chunk = (int)(ctx->chunk < img_count ? ctx->chunk : img_count);
-    // workspace: composites of the candidates one chunk can touch | chunk images CHW | chunk logits | net scratch
+    // workspace: composites of the candidates one chunk can touch | chunk logits | net scratch.  The warp kernel writes
+    // the classifier's NHWC4 input (GTSRBNet: after conv1_1 + ReLU) straight into the net scratch: no CHW image buffer,
+    // no layout-change kernel in between.
     const int max_cand = (int)((chunk + T - 1) / T + 1);
     const size_t per_cand = (size_t)xf->nslots * H * W * 16;
     const size_t att_bytes = gr_align(per_cand * (size_t)(max_cand < C ? max_cand : C));
-    const size_t x_bytes = gr_align((size_t)chunk * 3072 * sizeof(float));
     const size_t lg_bytes = gr_align((size_t)chunk * ncls * sizeof(float));
     const size_t net_bytes = net_workspace_bytes(m, chunk);
-    if ((rc = gr_ws_reserve(ctx, att_bytes + x_bytes + lg_bytes + net_bytes, stream))) return rc;
+    if ((rc = gr_ws_reserve(ctx, att_bytes + lg_bytes + net_bytes, stream))) return rc;
     float* att = (float*)ctx->ws;
-    float* xb = (float*)(ctx->ws + att_bytes);
-    float* lg = (float*)(ctx->ws + att_bytes + x_bytes);
-    char* nws = ctx->ws + att_bytes + x_bytes + lg_bytes;
+    float* lg = (float*)(ctx->ws + att_bytes);
+    char* nws = ctx->ws + att_bytes + lg_bytes;
+    const float* c11 = nullptr;
+    const int in_mode = net_input_mode(m, &c11);
     int have_lo = -1, have_hi = -1;     // candidates whose composites are currently in `att`
     for (int64_t n0 = img_begin; n0 < img_begin + img_count; n0 += chunk) {
         int nb = (int)(img_begin + img_count - n0 < chunk ? img_begin + img_count - n0 : chunk);
@@ -419,9 +423,9 @@ extern "C" int gr_tr_hits(gr_ctx* ctx, gr_model* m, const float* img, int H, int
                                    nh, nw, lbd, xf, att, st))) return rc;
             have_lo = c_lo; have_hi = c_hi;
         }
-        if ((rc = px_warp_net(ctx, att, H, W, xf, n0, nb, have_lo, normalize, 32, xb, st))) return rc;
+        if ((rc = px_warp_net(ctx, att, H, W, xf, n0, nb, have_lo, normalize, 32, net_input_x4(nws), st, in_mode, c11))) return rc;
         float* lg_out = logits ? logits + (size_t)n0 * ncls : lg;
-        if ((rc = net_forward(ctx, m, xb, nb, lg_out, nws, net_bytes, st))) return rc;
+        if ((rc = net_forward(ctx, m, nullptr, nb, lg_out, nws, net_bytes, st))) return rc;
         if ((rc = net_hits(ctx, lg_out, nb, ncls, n0, T, target, hits, preds ? preds + n0 : nullptr, st))) return rc;
     }
     return GR_OK;

@@ -38,6 +38,9 @@ struct XformDev {
     int32_t crop_x, crop_y;
     int32_t slot;                // index of the composite (blur variant) this transform samples
     int32_t bw0;
+    int32_t sep;                 // 1: Mi[1] == 0 and Mi[7] == 0 (every rotation about the y axis, perspective_transform.py:16-29):
+                                 //    source x and the projective divide depend on the destination COLUMN only
+    int32_t pad_;
     uint8_t lut[256];
 };
 
@@ -73,13 +76,21 @@ int px_composite(gr_ctx*, const float* img, int H, int W, const float* masks, co
 int px_composite_from_pert(gr_ctx*, const float* img, const float* mask_lg, const float* pert, int H, int W,
                            const gr_xforms* xf, float* att, hipStream_t);
 // images n in [n_begin, n_begin+count): candidate n/T (composite index n/T - cand0), transform n%T.
-// out_chw != null: [count,3,net,net] CHW f32.
+// out_mode GR_OUT_CHW: out = [count,3,net,net] CHW f32 (the reference's network input).
+// GR_OUT_NHWC4 (net == 32 only): out = [count,32,32,4] (r,g,b,0), the classifiers' input layout;
+// GR_OUT_NHWC4_C11 (net == 32 only): the same after GTSRBNet's conv1_1 (1x1, c11 = 9 weights + 3 biases, dev) + ReLU.
+enum { GR_OUT_CHW = 0, GR_OUT_NHWC4 = 1, GR_OUT_NHWC4_C11 = 2 };
 int px_warp_net(gr_ctx*, const float* att, int H, int W, const gr_xforms* xf, int64_t n_begin, int count, int cand0,
-                int normalize, int net, float* out_chw, hipStream_t);
+                int normalize, int net, float* out, hipStream_t, int out_mode = GR_OUT_CHW, const float* c11 = nullptr);
 
 // ---- nets.hip ----
 struct gr_model;
+// x_chw == nullptr: the NHWC4 input (net_input_mode's layout) is already in place at net_input_x4(ws)
 int net_forward(gr_ctx*, gr_model*, const float* x_chw, int N, float* logits, char* ws, size_t ws_bytes, hipStream_t);
+// where and how a fused producer (the warp kernel) hands the classifier its input: [N,32,32,4] floats at the start of ws;
+// mode = GR_OUT_NHWC4_C11 with *c11 set for GTSRBNet (conv1_1 + ReLU applied by the producer), GR_OUT_NHWC4 for WideResNet
+static inline float* net_input_x4(char* ws) { return (float*)ws; }
+int net_input_mode(const gr_model*, const float** c11);
 size_t net_workspace_bytes(const gr_model*, int N);
 int net_argmax(gr_ctx*, const float* logits, int N, int ncls, int64_t* preds, hipStream_t);
 int net_hits(gr_ctx*, const float* logits, int N, int ncls, int64_t n_begin, int T, int target, int32_t* hits,

@@ -730,7 +730,7 @@ static int gtsrb_forward(gr_ctx* ctx, gr_model* m, const float* x, int N, float*
     float* x4 = ws;
     float* A = x4 + (size_t)N * 4096;
     float* Bf = A + (size_t)N * 32768;
-    {
+    if (x) {                                 // x == nullptr: the warp kernel already wrote relu(conv1_1(.)) into x4
         ProfScope ps_(ctx, "k_input_nhwc4<conv1_1>", st, 2.0 * N * 1024 * 9, (double)N * 1024 * 28);
         hipLaunchKernelGGL(k_input_nhwc4<true>, dim3((N * 1024 + 255) / 256), dim3(256), 0, st, x, m->c11, N, (float4*)x4);
     }
@@ -804,8 +804,9 @@ static int wrn_forward(gr_ctx* ctx, gr_model* m, const float* x, int N, float* l
     float* u = o + (size_t)N * big;          // relu(bn2(conv1))
     float* s = u + (size_t)N * big;          // shortcut conv
     float* y = s + (size_t)N * big;          // next raw
-    hipLaunchKernelGGL(k_input_nhwc4<false>, dim3((N * 1024 + 255) / 256), dim3(256), 0, st, x, (const float*)nullptr, N,
-                       (float4*)x4);
+    if (x)
+        hipLaunchKernelGGL(k_input_nhwc4<false>, dim3((N * 1024 + 255) / 256), dim3(256), 0, st, x, (const float*)nullptr, N,
+                           (float4*)x4);
     GR_HIP(ctx, hipGetLastError());
     int rc;
     const size_t nb = m->blocks.size();
@@ -968,6 +969,12 @@ int net_input_grad(gr_ctx* ctx, gr_model* m, const float* x, int N, int target, 
     hipLaunchKernelGGL(k_input_grad, blocks((size_t)N * 1024), dim3(256), 0, st, gB, (const float4*)x4, m->c11, N, gx);
     GR_HIP(ctx, hipGetLastError());
     return GR_OK;
+}
+
+int net_input_mode(const gr_model* m, const float** c11) {
+    if (m->kind == 1) { *c11 = m->c11; return GR_OUT_NHWC4_C11; }
+    *c11 = nullptr;
+    return GR_OUT_NHWC4;
 }
 
 int net_forward(gr_ctx* ctx, gr_model* m, const float* x, int N, float* logits, char* ws, size_t ws_bytes, hipStream_t st) {

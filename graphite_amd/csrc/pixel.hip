@@ -256,18 +256,21 @@ __device__ __forceinline__ void warp_gamma_rgbx(const float4* __restrict__ att, 
 // xcd_map: workgroups are dealt round-robin to the 8 XCDs (each with its own L2); with the map on, XCD x gets the
 // x-th contiguous eighth of the launch's images, i.e. (for T ~ chunk/8) the images of ONE candidate, whose composites
 // then stay in that XCD's L2 instead of every L2 streaming every candidate's composites.
-__global__ __launch_bounds__(256) void k_warp_net(const float* __restrict__ att_all, int H, int W, int nslots,
-                                                  const XformDev* __restrict__ xf, int T, long long n_begin, int cand0,
-                                                  int normalize, int net, int count, int xcd_map, float* __restrict__ out) {
+__device__ __forceinline__ int warp_local_index(int count, int xcd_map) {
+    if (!xcd_map) return blockIdx.x;
+    const int per = (count + 7) >> 3;
+    return (blockIdx.x & 7) * per + (blockIdx.x >> 3);   // >= count for the padding workgroups of the rounded-up grid
+}
+
+// Generic network size (net x net, CHW output): every warped pixel runs the full coordinate computation.
+__global__ __launch_bounds__(256) void k_warp_net_any(const float* __restrict__ att_all, int H, int W, int nslots,
+                                                      const XformDev* __restrict__ xf, int T, long long n_begin, int cand0,
+                                                      int normalize, int net, int count, int xcd_map, float* __restrict__ out) {
     __shared__ double s_Mi[9];
     __shared__ float s_lutf[256];
     __shared__ int s_par[4];
-    int local = blockIdx.x;
-    if (xcd_map) {
-        const int per = (count + 7) >> 3;
-        local = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
-        if (local >= count) return;               // uniform for the workgroup; grid is rounded up to 8 * per
-    }
+    const int local = warp_local_index(count, xcd_map);
+    if (local >= count) return;                   // uniform for the workgroup
     const long long n = n_begin + local;
     const int cand = (int)(n / T) - cand0, t = (int)(n % T);
     const XformDev* x = xf + t;
@@ -303,6 +306,140 @@ __global__ __launch_bounds__(256) void k_warp_net(const float* __restrict__ att_
         for (int c = 0; c < 3; c++) {
             float v = clamp01(r[c]);
             o[c * net * net + p] = normalize ? v - 0.5f : v;
+        }
+    }
+}
+
+// The 32x32 network input (every BASELINE configuration), fused with the classifiers' input stage.
+// A transform of the reference is a rotation about the image's y axis (perspective_transform.py:16-29), so the inverse
+// matrix has Mi[1] == Mi[7] == 0: the projective divide, the source x and its 1/32-pixel fraction depend on the
+// destination COLUMN only.  The 64 warped columns an image needs (two per output column) are worked out ONCE per image
+// in double precision -- the expensive part, an IEEE f64 division per warped pixel, drops from 4096 to 64 per image --
+// and kept in LDS; what remains per warped pixel is the row coordinate (two f64 adds, one multiply, one rounding).
+// Every intermediate is computed by the same operations in the same order as warp_taps() (adding Mi[1]*y = +-0 or
+// Mi[7]*y = +-0 changes no value), so the results stay bit-identical; transforms whose matrix is not of that form
+// (sep == 0) take the per-pixel path inside the same kernel.
+struct WarpCol {
+    double Wd;          // 32 / W of the column (0 when W == 0)
+    double A, B;        // Mi[3]*xb and Mi[3]*x1: the column's share of Y0
+    int sx0, sx1;       // clipped source columns
+    float fx;           // fraction (X & 31) / 32
+    int pad_;
+};
+
+template <int OUT>
+__global__ __launch_bounds__(256) void k_warp_net32(const float* __restrict__ att_all, int H, int W, int nslots,
+                                                    const XformDev* __restrict__ xf, int T, long long n_begin, int cand0,
+                                                    int normalize, int count, int xcd_map, const float* __restrict__ c11,
+                                                    float* __restrict__ out) {
+    constexpr int net = 32;
+    __shared__ double s_Mi[9];
+    __shared__ float s_lutf[256];
+    __shared__ WarpCol s_col[64];
+    __shared__ Tap s_tx[32], s_ty[32];
+    __shared__ float s_c11[12];
+    const int local = warp_local_index(count, xcd_map);
+    if (local >= count) return;                   // uniform for the workgroup
+    const long long n = n_begin + local;
+    const int cand = (int)(n / T) - cand0, t = (int)(n % T);
+    const XformDev* x = xf + t;
+    const int tid = threadIdx.x;
+    const int cw = x->crop_x, ch = x->crop_y, bw0 = x->bw0, sep = x->sep;
+    const bool same = (cw == net && ch == net);
+    const double scx = 1.0 / ((double)net / (double)cw), scy = 1.0 / ((double)net / (double)ch);
+    s_lutf[tid] = clamp01((float)((double)x->lut[tid] / 255.0));
+    if (tid < 9) s_Mi[tid] = x->Mi[tid];
+    if (OUT == GR_OUT_NHWC4_C11 && tid >= 16 && tid < 28) s_c11[tid - 16] = c11[tid - 16];
+    if (tid >= 64 && tid < 96) {
+        const int o = tid - 64;
+        Tap tx, ty;
+        if (same) { tx.i0 = tx.i1 = ty.i0 = ty.i1 = o; tx.w0 = ty.w0 = 1.f; tx.w1 = ty.w1 = 0.f; }
+        else { tx = tap_h(o, cw, scx); ty = tap_v(o, ch, scy); }
+        s_tx[o] = tx; s_ty[o] = ty;
+    }
+    if (tid < 64 && sep) {                        // warped column (tid & 1 ? i1 : i0) of output column tid >> 1
+        const int ox = tid >> 1;
+        int xc;
+        if (same) xc = ox;
+        else { Tap tx = tap_h(ox, cw, scx); xc = (tid & 1) ? tx.i1 : tx.i0; }
+        const double m0 = x->Mi[0], m2 = x->Mi[2], m3 = x->Mi[3], m6 = x->Mi[6], m8 = x->Mi[8];
+        const int xb = (xc / bw0) * bw0, x1 = xc - xb;
+        const double X0 = m0 * xb + m2;           // (Mi[0]*xb + Mi[1]*y) + Mi[2] with Mi[1]*y == +-0
+        const double W0 = m6 * xb + m8;           // (Mi[6]*xb + Mi[7]*y) + Mi[8] with Mi[7]*y == +-0
+        double Wd = W0 + m6 * x1;
+        Wd = 32.0 * (Wd != 0.0 ? 1.0 / Wd : 0.0);
+        const int X = cv_round_sat((X0 + m0 * x1) * Wd);
+        const int sx = sat_short(X >> 5);
+        WarpCol c;
+        c.Wd = Wd; c.A = m3 * xb; c.B = m3 * x1;
+        c.sx0 = clipi(sx, 0, W); c.sx1 = clipi(sx + 1, 0, W);
+        c.fx = (float)(X & 31) * (1.f / 32.f);
+        c.pad_ = 0;
+        s_col[tid] = c;
+    }
+    __syncthreads();
+    const size_t pl = (size_t)H * W;
+    const float4* att = reinterpret_cast<const float4*>(att_all) + ((size_t)cand * nslots + x->slot) * pl;
+    const double m4 = s_Mi[4], m5 = s_Mi[5];
+    const int nq = same ? 1 : 2;
+#pragma unroll 1
+    for (int p = tid; p < net * net; p += 256) {
+        const int oy = p >> 5, ox = p & 31;
+        const Tap tx = s_tx[ox], ty = s_ty[oy];
+        float g[2][2][3];
+        for (int jy = 0; jy < nq; jy++) {
+            const int y = jy ? ty.i1 : ty.i0;
+            for (int jx = 0; jx < nq; jx++) {
+                if (sep) {
+                    const WarpCol c = s_col[ox * 2 + jx];
+                    const double Y0 = (c.A + m4 * y) + m5;
+                    const int Y = cv_round_sat((Y0 + c.B) * c.Wd);
+                    const int sy = sat_short(Y >> 5);
+                    const float fy = (float)(Y & 31) * (1.f / 32.f), fx = c.fx;
+                    const float w0 = (1.f - fy) * (1.f - fx), w1 = (1.f - fy) * fx, w2 = fy * (1.f - fx), w3 = fy * fx;
+                    const int r0 = clipi(sy, 0, H) * W, r1 = clipi(sy + 1, 0, H) * W;
+                    const float4 a = att[r0 + c.sx0], b = att[r0 + c.sx1], cc = att[r1 + c.sx0], d = att[r1 + c.sx1];
+                    g[jy][jx][0] = gamma_stage_f(a.x * w0 + b.x * w1 + cc.x * w2 + d.x * w3, s_lutf);
+                    g[jy][jx][1] = gamma_stage_f(a.y * w0 + b.y * w1 + cc.y * w2 + d.y * w3, s_lutf);
+                    g[jy][jx][2] = gamma_stage_f(a.z * w0 + b.z * w1 + cc.z * w2 + d.z * w3, s_lutf);
+                } else {
+                    warp_gamma_rgbx(att, s_Mi, bw0, jx ? tx.i1 : tx.i0, y, H, W, s_lutf, g[jy][jx]);
+                }
+            }
+        }
+        float v[3];
+        for (int c = 0; c < 3; c++) {
+            float r;
+            if (same) r = g[0][0][c];
+            else {
+                const float h0 = g[0][0][c] * tx.w0 + g[0][1][c] * tx.w1;
+                const float h1 = g[1][0][c] * tx.w0 + g[1][1][c] * tx.w1;
+                r = h0 * ty.w0 + h1 * ty.w1;
+            }
+            r = clamp01(r);
+            v[c] = normalize ? r - 0.5f : r;
+        }
+        if (OUT == GR_OUT_CHW) {
+            float* o = out + (size_t)local * 3 * net * net;
+            for (int c = 0; c < 3; c++) o[c * net * net + p] = v[c];
+        } else {
+            float4 o4;
+            if (OUT == GR_OUT_NHWC4_C11) {        // GTSRBNet conv1_1 (1x1) + ReLU, the arithmetic of k_input_nhwc4<true>
+                float r[3];
+#pragma unroll
+                for (int k = 0; k < 3; k++) {
+                    float a = 0.f;
+                    a = fmaf(v[0], s_c11[k * 3 + 0], a);
+                    a = fmaf(v[1], s_c11[k * 3 + 1], a);
+                    a = fmaf(v[2], s_c11[k * 3 + 2], a);
+                    a = a + s_c11[9 + k];
+                    r[k] = a > 0.f ? a : 0.f;
+                }
+                o4 = make_float4(r[0], r[1], r[2], 0.f);
+            } else {
+                o4 = make_float4(v[0], v[1], v[2], 0.f);
+            }
+            reinterpret_cast<float4*>(out)[(size_t)local * (net * net) + p] = o4;
         }
     }
 }
@@ -388,16 +525,27 @@ int px_composite_from_pert(gr_ctx* ctx, const float* img, const float* mask_lg, 
 }
 
 int px_warp_net(gr_ctx* ctx, const float* att, int H, int W, const gr_xforms* xf, int64_t n_begin, int count, int cand0,
-                int normalize, int net, float* out_chw, hipStream_t st) {
+                int normalize, int net, float* out, hipStream_t st, int out_mode, const float* c11) {
     if (count <= 0) return GR_OK;
+    if (out_mode != GR_OUT_CHW && net != 32) return gr_fail(ctx, GR_EINVAL, "px_warp_net: NHWC4 output needs net == 32");
+    if (out_mode == GR_OUT_NHWC4_C11 && !c11) return gr_fail(ctx, GR_EINVAL, "px_warp_net: conv1_1 parameters missing");
     // algorithmic bytes: 12 B/px written per image + 336 B of transform descriptor read
     ProfScope ps_(ctx, "k_warp_net", st, 0.0, (double)count * (12.0 * net * net + 336.0));
     static int xcd_map = -1;                     // GRAPHITE_WARP_XCD=0 turns the XCD-aware block order off (A/B runs)
     if (xcd_map < 0) { const char* e = getenv("GRAPHITE_WARP_XCD"); xcd_map = (e && e[0] == '0') ? 0 : 1; }
     const int use_map = (xcd_map && count >= 64) ? 1 : 0;
     const int grid = use_map ? 8 * ((count + 7) / 8) : count;
-    hipLaunchKernelGGL(k_warp_net, dim3(grid), dim3(256), 0, st, att, H, W, xf->nslots, xf->dev, xf->T,
-                       (long long)n_begin, cand0, normalize, net, count, use_map, out_chw);
+    if (net != 32) {
+        hipLaunchKernelGGL(k_warp_net_any, dim3(grid), dim3(256), 0, st, att, H, W, xf->nslots, xf->dev, xf->T,
+                           (long long)n_begin, cand0, normalize, net, count, use_map, out);
+    } else {
+#define WN(M) hipLaunchKernelGGL(k_warp_net32<M>, dim3(grid), dim3(256), 0, st, att, H, W, xf->nslots, xf->dev, xf->T, \
+                                 (long long)n_begin, cand0, normalize, count, use_map, c11, out)
+        if (out_mode == GR_OUT_CHW) WN(GR_OUT_CHW);
+        else if (out_mode == GR_OUT_NHWC4) WN(GR_OUT_NHWC4);
+        else WN(GR_OUT_NHWC4_C11);
+#undef WN
+    }
     GR_HIP(ctx, hipGetLastError());
     return GR_OK;
 }
