@@ -2,9 +2,10 @@
 
 Per iteration the reference evaluates q = 10 random directions one after the other (:87-101); the
 directions do not depend on each other's results, so they are drawn up front (same torch RNG
-stream, same order) and evaluated in ONE fused launch (10 candidates x T transforms).  Everything
-else -- gradient accumulation order, back-tracking ladder, budget rule, query accounting -- follows
-the reference step by step.
+stream, same order) and evaluated in ONE fused launch (10 candidates x T transforms); without
+back-tracking the step's own evaluation and the NEXT iteration's directions share a launch (11 candidates).
+Everything else -- gradient accumulation order, back-tracking ladder, budget rule, query accounting --
+follows the reference step by step.
 """
 import torch
 
@@ -29,19 +30,34 @@ def boost(model, x0_large, y0, mask, target_example, target=None, beta=1, iterat
     theta, eps = best_theta.clone(), best_eps
     opt_count = 0
     iters_taken = 0
+    q = 10
+    # Without back-tracking the step of iteration i is taken whatever its evaluation says (:151-160), so the q directions
+    # of iteration i+1 (drawn from the same RNG stream right after it) can ride in the SAME launch as the step's own
+    # evaluation: 11 candidates instead of two dependent launches of 1 and 10.  Only when the loop is known to go on
+    # (the budget rule counts queries, which are deterministic) and the evaluator may speculate.
+    fuse = (not bt) and getattr(ev, "speculate", False)
+    carried = None                                           # (us, ttts, results) evaluated ahead by the previous launch
+
+    def draw(th):
+        us, ttts = [], []
+        for _ in range(q):                                   # same RNG draws, same order as :88-90
+            u = torch.randn(th.size()).type(torch.FloatTensor) * mask
+            u = u / torch.norm(u)
+            us.append(u)
+            ttts.append(th + beta * u)
+        return us, ttts
+
     for i in range(iterations):
         iters_taken += 1
         gradient = torch.zeros(theta.size())
-        q = 10
         min_g1 = float('inf')
         min_ttt = None
-        us, ttts = [], []
-        for _ in range(q):                                   # same RNG draws, same order as :88-90
-            u = torch.randn(theta.size()).type(torch.FloatTensor) * mask
-            u = u / torch.norm(u)
-            us.append(u)
-            ttts.append(theta + beta * u)
-        res = ev.errors([mask] * q, ttts)                    # one launch for the q directions
+        if carried is None:
+            us, ttts = draw(theta)
+            res = ev.errors([mask] * q, ttts)                # one launch for the q directions
+        else:
+            us, ttts, res = carried
+            carried = None
         for u, ttt, (eps_ttt, opt_ct) in zip(us, ttts, res):
             opt_count += opt_ct
             gradient += (eps_ttt - eps) / beta * u
@@ -80,7 +96,17 @@ def boost(model, x0_large, y0, mask, target_example, target=None, beta=1, iterat
                 new_theta, new_eps = min_ttt, min_g1
         else:
             new_theta = theta - eta * gradient
-            new_eps, opt_ct = ev.error(mask, new_theta)
+            # will the loop go on after this step?  (:163 with this step's num_xforms queries added; :165 depends on the
+            # step's own result, so that exit is never speculated over)
+            goes_on = (i + 1 < iterations and
+                       not (opt_count + num_xforms + query_count + num_xforms * 11) > (budget_factor * num_xforms) and
+                       not (square_mask and i == 0 and early_boost_exit))
+            if fuse and goes_on:
+                nus, nttts = draw(new_theta)
+                both = ev.errors([mask] * (q + 1), [new_theta] + nttts)
+                (new_eps, opt_ct), carried = both[0], (nus, nttts, both[1:])
+            else:
+                new_eps, opt_ct = ev.error(mask, new_theta)
             opt_count += opt_ct
 
         if new_eps < best_eps:
@@ -91,6 +117,7 @@ def boost(model, x0_large, y0, mask, target_example, target=None, beta=1, iterat
             break
         if square_mask and i == 0 and best_eps >= 0.95 and early_boost_exit:
             break
+    assert carried is None, "a speculated direction batch was left unused"
 
     adv_example = ev.add_noise(x0_large, mask, 1.0, best_theta, clip=(model_type == 'GTSRB'))
     mask_large = ev.resize(mask, x0_large.size()[1], x0_large.size()[2])

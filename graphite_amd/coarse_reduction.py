@@ -6,8 +6,9 @@
 
 Decisions and query counts are the reference's: the leftmost-pivot binary search (including its
 final re-evaluation of the pivot, :163) is replayed evaluation by evaluation; each evaluation is one
-fused GPU pass over the transforms.  Pivot evaluations are sequentially dependent and only ~log2(n)
-many, so they are not speculated (a 100-image launch is latency-bound on an MI355X).
+fused GPU pass over the transforms.  A 100-image launch is latency-bound on an MI355X, so with the fused
+evaluator the pivots of the next three levels (7 candidates, every outcome) share a launch and the search
+is replayed on the cached results; a duck-typed classifier is queried pivot by pivot as in the reference.
 """
 import time
 
@@ -76,37 +77,64 @@ def perform_linear_coarse_reduction(patches, err_threshold, lbl_v, lbl_t, img_t_
     return j, best_mask, best_tr, tot
 
 
+COARSE_SPEC_DEPTH = 3     # levels of the binary search evaluated per launch (2**3 - 1 = 7 pivots) when speculation is allowed
+
+
 def perform_binary_coarse_reduction(patches, err_threshold, lbl_v, lbl_t, img_t_small, img_v_small, img_v, model, xforms,
                                     start_mask, pt_file, net_size, direction="forward", model_type='GTSRB',
                                     init_theta=None, _evaluator=None):
     ev = make_evaluator(_evaluator, model, img_v, xforms, pt_file, model_type, lbl_v, lbl_t)
     tot = 0
-    # prefix unions are built incrementally (the reference rebuilds them from scratch per pivot, :128-136)
-    prefix = {0: torch.zeros(start_mask.size())}
+    n = len(patches)
+    # prefix unions: mask_upto(k) = union of the first k patches (the reference rebuilds it from scratch per pivot,
+    # :128-136); patches are 0/1, so the union is "running sum > 0"
+    csum = torch.cumsum(torch.stack([torch.zeros(start_mask.size()) + p for p in patches]), 0) if n else None
 
     def mask_upto(pivot):
-        k = max(p for p in prefix if p <= pivot)
-        m = prefix[k]
-        for j in range(k, pivot):
-            m = _union(m, patches[j])
-        prefix[pivot] = m
-        return m.clone()
+        if pivot <= 0:
+            return torch.zeros(start_mask.size())
+        return torch.where(csum[pivot - 1] > 0, torch.ones(start_mask.size()), torch.zeros(start_mask.size()))
 
-    def tr_at(pivot):
+    # A launch of ONE 100-image candidate leaves the GPU mostly idle, so with an evaluator that may speculate the pivots
+    # of the next COARSE_SPEC_DEPTH levels (every outcome) are evaluated together and the search is replayed on the
+    # cached results.  Only pivots the reference visits are counted (tot), its final re-evaluation included (:163).
+    spec = getattr(ev, "speculate", False) and hasattr(ev, "errors")
+    cache = {}
+
+    def subtree(lo, hi, depth):
+        if lo > hi or depth == 0:
+            return []
+        mi = lo + (hi - lo) // 2
+        out = [mi]
+        if mi > 0:
+            out += subtree(lo, mi - 1, depth - 1)
+        return out + subtree(mi + 1, hi, depth - 1)
+
+    def tr_at(pivot, lo=None, hi=None):
         nonlocal tot
-        m = mask_upto(pivot)
-        success_rate, query_ct = ev.error(m, _theta(init_theta, img_t_small, img_v_small, m))
+        if not spec:
+            m = mask_upto(pivot)
+            success_rate, query_ct = ev.error(m, _theta(init_theta, img_t_small, img_v_small, m))
+            tot += query_ct
+            return 1 - success_rate, m
+        if pivot not in cache:
+            want = [pivot] if lo is None else subtree(lo, hi, COARSE_SPEC_DEPTH)
+            want = sorted(set(p for p in want if p not in cache) | {pivot})
+            masks = [mask_upto(p) for p in want]
+            res = ev.errors(masks, [_theta(init_theta, img_t_small, img_v_small, m) for m in masks])
+            for p, m, (success_rate, query_ct) in zip(want, masks, res):
+                cache[p] = (1 - success_rate, query_ct, m)
+        tr, query_ct, m = cache[pivot]
         tot += query_ct
-        return 1 - success_rate, m
+        return tr, m.clone()
 
-    n = len(patches)
     threshold = 1 - err_threshold
     mi = 0 if n == 1 else -1
     if mi < 0:
         lo, hi = 0, n - 1
         while lo <= hi:
             mi = lo + (hi - lo) // 2
-            score, _ = tr_at(mi)
+            score, _ = tr_at(mi, lo, hi)
             if score >= threshold:
                 if mi > 0:
                     hi = mi - 1

@@ -426,6 +426,7 @@ __global__ void k_argmax_hits(const float* __restrict__ logits, int N, int ncls,
 // layer dispatch
 // ---------------------------------------------------------------------------------------------
 static bool use_igemm_convs();
+static bool small_launch_ok();
 static int halo_variant(int layer);
 static int bf16_variant(int layer);
 
@@ -537,6 +538,13 @@ static int run_conv(gr_ctx* ctx, const Layer& L, const float* in, int B, int H, 
         ProfScope ps_(ctx, pname, st, flops, bytes);                                                              \
         e = launch_conv_igemm<BK_, WM_, WN_, TM_, TN_, POOL_>(p, st);                                             \
     } while (0)
+    // Small launches (the attack's 100-image evaluations: M = 100 .. 1000 rows of a linear layer): a 128x128 tile would
+    // leave 8 workgroups walking K with 64 MFMAs per wave and chunk while 248 CUs idle.  128x32 tiles put one 32x32
+    // tile on each wave (a quarter of the chain time) and 32 workgroups per 128 rows on the chip.  Same k-ascending
+    // chain per output: bit-identical results.
+    if (small_launch_ok() && p.M <= 4096 && bk == 32 && !pool && L.KH == 1 && L.KW == 1 && H == 1 && W == 1 && L.NP % 32 == 0 && !L.kchunk) {
+        GO(32, 4, 1, 1, 1, false);
+    } else
     if (bn == 32) {
         if (bk == 32) { if (pool) GO(32, 4, 1, 2, 1, true); else GO(32, 4, 1, 2, 1, false); }
         else if (bk == 16 && !pool) GO(16, 4, 1, 2, 1, false);
@@ -601,10 +609,17 @@ static int run_gtsrb_halo(gr_ctx* ctx, const Layer& L, int layer, const float* i
     snprintf(pname, sizeof(pname), "k_conv_halo<conv%d_%d>", 2 + layer / 2, 1 + layer % 2);
     ProfScope ps_(ctx, pname, st, flops, bytes);
     hipError_t e = hipErrorInvalidValue;
-    const int v = halo_variant(layer);
+    int v = halo_variant(layer);
+    // Small launches (one or two 100-transform candidates of an attack): variant 7 = 8 wavefronts with ONE
+    // 32x32 tile each, twice as many workgroups -- the MFMA chain a wave walks is a quarter to a half as long, which is
+    // what a launch that cannot fill the chip pays for.  Same chains per output: bit-identical.
+    // Measured (scripts/small_launch.py): conv3_1 gains up to B = 128, conv4_1 up to B = 256; conv3_2 / conv4_2 do not.
+    if (v == 0 && small_launch_ok() && ((layer == 2 && B <= 128) || (layer == 4 && B <= 256))) v = 7;
     //                            CIN CPH KH KW  PS  TH  TW NIMG WM WN TM TN  KU   NP  POOL
 #define HL(...) e = launch_conv_halo<__VA_ARGS__>(p, st)
     switch (layer * 8 + v) {            // variant 0 of each layer = the fastest measured (profiles/r01_tune_*.log)
+    case 2 * 8 + 7: HL( 32, 32, 5, 5,  33,  8, 16, 1,  4, 2, 1, 1,  8,  64, false, 0); break;   // conv3_1, small launch
+    case 4 * 8 + 7: HL( 64, 64, 5, 5,  65,  8,  8, 1,  2, 4, 1, 1, 16, 128, false, 0); break;   // conv4_1, small launch
     case 0 * 8 + 0: HL( 20,  4, 5, 1,   4, 16, 32, 1,  4, 1, 4, 1,  5,  32, false, 1); break;   // conv2_1
     case 0 * 8 + 1: HL( 20,  4, 5, 1,   4, 16, 32, 1,  4, 1, 4, 1,  5,  32, false, 0); break;
     case 0 * 8 + 2: HL( 20,  4, 5, 1,   4,  8, 32, 1,  4, 1, 2, 1,  5,  32, false, 0); break;
@@ -720,6 +735,11 @@ static int run_fc_bf16(gr_ctx* ctx, const Layer& L, const char* name, const floa
 // Measured per link (profiles/r01_bf16_tune.md): a bf16 INPUT costs the Cin <= 64 conv kernels registers and resident waves
 // (conv2_2 +0.9 ms, conv3_1 +0.9, conv3_2 +0.6, conv4_1 +0.3 per 32,000 images), so only the last three links are bf16.
 #define BF16_LINKS_DEFAULT 0x70
+static bool small_launch_ok() {      // GRAPHITE_SMALL=0 turns the small-launch tilings off (A/B runs)
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("GRAPHITE_SMALL"); v = (e && e[0] == '0') ? 0 : 1; }
+    return v == 1;
+}
 static bool use_igemm_convs() {      // GRAPHITE_CONV=igemm selects the im2col-chunk kernels for A/B runs
     static int v = -1;
     if (v < 0) { const char* e = getenv("GRAPHITE_CONV"); v = (e && strcmp(e, "igemm") == 0) ? 1 : 0; }

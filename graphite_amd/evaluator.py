@@ -28,6 +28,12 @@ class TREvaluator:
         self._img_d = _hip.to_dev(image)
         self._xf = _hip.xform_table(build_xform_table(transforms, image.shape[2], image.shape[1], pt_file)) if self.n else None
         self._fused = hasattr(model, "hip_model")
+        # Speculative batching (fine-reduction windows, boost's step + next directions in one launch) evaluates candidates
+        # the sequential algorithm may never ask for.  That is free for the fused HIP classifier; a duck-typed model
+        # (anything with .predict) must see exactly the reference's predict() calls in the reference's order, so the
+        # drivers speculate only when this is true.
+        self.speculate = self._fused
+        self.issued = 0          # images really sent to the classifier (>= the reference-equivalent query count)
 
     # ---- candidates -> [(error_rate, queries)] -------------------------------------------------
     def errors(self, masks, thetas):
@@ -37,6 +43,7 @@ class TREvaluator:
         if C == 0:
             return []
         N = self.n
+        self.issued += C * max(N, 1)
         if self._fused and N > 0:
             from .engine import tr_hits
             if self.target is not None:

@@ -12,7 +12,9 @@ is derived from -- so it is evaluated in speculative windows: the next W candida
 assuming the outcomes so far repeat (all-reject from the current mask, or an all-accept chain),
 evaluated in one launch, and consumed up to and including the first misprediction.  Decisions,
 returned masks and the REPORTED query count are exactly the reference's: only evaluations the
-reference would have made are counted.
+reference would have made are counted.  The images really classified (more, because of discarded
+speculation) are counted by the evaluator (`TREvaluator.issued`; `attack_network` reports both).  An
+evaluator with `speculate = False` (every duck-typed classifier) is never sent a speculative candidate.
 """
 import importlib
 import pickle
@@ -162,7 +164,11 @@ def get_fine_reduced_mask(start_mask, object_size, patches, indices, img_v, img_
     best_tr, best_mask = init_tr, start_mask
     ones = torch.ones(start_mask.size())
     last_accept = True                                   # first window speculates an accept chain
-    win = max(1, min(FINE_WINDOW, 2 * FINE_WINDOW_MIN))
+    # an evaluator that must not see candidates the sequential algorithm would not evaluate (a duck-typed classifier
+    # behind .predict, whose query count is the attack's cost) gets windows of ONE: no speculation
+    wmax = FINE_WINDOW if getattr(ev, "speculate", True) else 1
+    wmin = min(wmax, FINE_WINDOW_MIN)
+    win = max(1, min(wmax, 2 * wmin))
 
     done = False
     while patches and not done:
@@ -207,7 +213,7 @@ def get_fine_reduced_mask(start_mask, object_size, patches, indices, img_v, img_
             last_accept = accepted
             if done or mispredicted:
                 break
-        win = min(FINE_WINDOW, 2 * win) if consumed == len(window) else max(min(FINE_WINDOW, FINE_WINDOW_MIN), win // 2)
+        win = min(wmax, 2 * win) if consumed == len(window) else max(wmin, win // 2)
         del patches[len(patches) - consumed:]
         del indices[len(indices) - consumed:]
     return best_score, best_tr, best_mask, reduction_query_ct

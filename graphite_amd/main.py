@@ -36,6 +36,12 @@ def attack_network(model, img_v, img_t, mask, lbl_v, lbl_t, pt_file, scorefile, 
     """Paths in (victim image, target image, hull mask), PNGs out; returns a dict with what the
     reference prints (transform robustness, mask pixels, queries) plus the tensors."""
     args = args or parsearguments.getarguments()
+    issued = []                                            # evaluators created on the way, for the issued-image count
+    if _evaluator is None:
+        def _evaluator(*a, **k):
+            ev = TREvaluator(*a, **k)
+            issued.append(ev)
+            return ev
     user = getpass.getuser()
     tag = (user + "_" + (image_id + "_" if image_id != '' else '') + str(lbl_v) + '_' + str(lbl_t) + '_' + str(reduceerror) +
            '_' + str(coarseerror) + '_' + str(args.coarse_mode) + '_' + scorefile + "_")
@@ -109,6 +115,9 @@ def attack_network(model, img_v, img_t, mask, lbl_v, lbl_t, pt_file, scorefile, 
     print("Final number of queries:", total_mask_q + total_boost_q)
     res.update(transform_robustness=tr_score, pixels=nbits, queries=total_mask_q + total_boost_q,
                mask_queries=total_mask_q, boost_queries=total_boost_q)
+    if issued:      # images really classified, discarded speculation included (`queries` is the reference-equivalent count)
+        res["queries_issued"] = int(sum(ev.issued for ev in issued))
+        print("Images classified including discarded speculation:", res["queries_issued"])
     return res
 
 

@@ -94,6 +94,22 @@ def get_transform_params(num_xforms, model_type='GTSRB', nps=False, baseline=Fal
 
 def gamma_table(gamma):
     """256-entry uint8 lighting table: trunc(clip((i/255)**gamma * 255, 0, 255))  (transforms.py:70-72)."""
+    # The reference evaluates Python's pow (libm) per entry and truncates.  numpy's vectorised power may differ from libm
+    # in the last bits, which matters only where the value sits on an integer boundary: those entries (within 1e-6 of an
+    # integer -- ten orders of magnitude above any pow rounding difference) are recomputed with Python's pow.
+    v = np.clip(np.power(_LEVELS, float(gamma)) * 255.0, 0.0, 255.0)
+    near = np.nonzero(np.abs(v - np.rint(v)) < 1e-6)[0]
+    t = v.astype(np.uint8)
+    for i in near:
+        t[i] = int(min(max(pow(i / 255.0, gamma) * 255.0, 0.0), 255.0))
+    return t
+
+
+_LEVELS = np.arange(256, dtype=np.float64) / 255.0
+
+
+def _gamma_table_scalar(gamma):
+    """The reference's loop, entry by entry (transforms.py:70-72); tests compare gamma_table against it."""
     t = np.empty(256, np.uint8)
     for i in range(256):
         t[i] = int(min(max(pow(i / 255.0, gamma) * 255.0, 0.0), 255.0))

@@ -7,8 +7,11 @@
 Return values are the reference's: `(1 - hits/len(imgs), len(imgs))`, i.e. the ERROR rate (not the
 transform robustness) and the number of classifier queries.  The model is duck-typed, as in the
 reference: anything with `.predict(batch) -> LongTensor[B]`.  Batches are 256 images, the
-reference's batch size, so a stateful / order-sensitive model sees the same calls; a graphite_amd
-model classifies each batch on the GPU (predict() uploads once, returns device labels).
+reference's batch size, so within ONE run_predictions call a stateful / order-sensitive model sees the
+reference's predict() calls; a graphite_amd model classifies each batch on the GPU (predict() uploads once,
+returns device labels).  Across calls the search drivers keep the reference's sequence of evaluations for
+such a model too: they speculate (evaluate candidates the sequential algorithm may discard) only through
+the fused HIP evaluator (`TREvaluator.speculate`), never through a duck-typed `.predict`.
 """
 import torch
 

@@ -17,3 +17,36 @@ def run():
 run()
 pr = cProfile.Profile(); pr.enable(); r = run(); torch.cuda.synchronize(); pr.disable()
 s = io.StringIO(); pstats.Stats(pr, stream=s).sort_stats("cumulative").print_stats(28); print(s.getvalue()[:5000])
+
+# ---- per-launch log: candidates per evaluator call and the wall time of each (upload + kernels + download) ----
+import time
+from graphite_amd import evaluator as E
+log = []
+_orig = E.TREvaluator.errors
+def _timed(self, masks, thetas):
+    t0 = time.perf_counter(); r = _orig(self, masks, thetas); log.append((len(r), time.perf_counter() - t0)); return r
+E.TREvaluator.errors = _timed
+t0 = time.perf_counter(); r = run(); torch.cuda.synchronize(); wall = time.perf_counter() - t0
+E.TREvaluator.errors = _orig
+import collections
+by = collections.OrderedDict()
+for c, dt in log:
+    k = by.setdefault(c, [0, 0.0]); k[0] += 1; k[1] += dt
+print("wall %.3f s, %d evaluator calls, %.3f s inside them, queries %d" % (wall, len(log), sum(d for _, d in log), r["queries"]))
+for c, (n, dt) in sorted(by.items()):
+    print("  C=%4d  calls %4d  total %.1f ms  per call %.3f ms  images/s %.0f" % (c, n, 1e3 * dt, 1e3 * dt / n, c * 100 * n / dt))
+
+# ---- the accept / reject sequence of the fine reduction (what a speculation policy has to predict) ----
+from graphite_amd import generate_mask as GM, score as S
+seq = []
+_sf = S.score_fn
+def _rec(*a, **k):
+    v = _sf(*a, **k)
+    if "best_score" in k:
+        seq.append("A" if v < k["best_score"] else "r")
+    return v
+S.score_fn = _rec
+run()
+S.score_fn = _sf
+print("fine reduction outcomes (%d evaluated):" % len(seq))
+print("".join(seq))

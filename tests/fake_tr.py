@@ -36,14 +36,17 @@ class FakeTR:
 class FakeEvaluator:
     """Same seam as graphite_amd.evaluator.TREvaluator, backed by FakeTR + the CPU oracle's image ops."""
 
-    def __init__(self, fake, oracle):
+    def __init__(self, fake, oracle, speculate=True):
         self.fake, self.oracle = fake, oracle
+        self.speculate = speculate        # may the drivers evaluate candidates the sequential algorithm might not ask for?
         self.launches = 0
         self.evaluated = 0
+        self.order = []                   # crc of every (mask, theta) evaluated, in order
 
     def errors(self, masks, thetas):
         self.launches += 1
         self.evaluated += len(masks)
+        self.order += [zlib.crc32(m.numpy().tobytes() + t.numpy().tobytes()) for m, t in zip(masks, thetas)]
         return [self.fake.err(m, t) for m, t in zip(masks, thetas)]
 
     def error(self, mask, theta):

@@ -138,3 +138,18 @@ def test_run_predictions_ragged_images():
     assert b.shape == (3, 3, 32, 32)
     assert b[1, :, :, :20].sum() == 3 * 32 * 20 and b[1, :, :, 20:].sum() == 0
     assert b[2].sum() == 3 * 64
+
+
+def test_gamma_table_vectorised_equals_the_reference_loop():
+    """gamma_table (numpy power + Python pow on the integer boundaries) == the reference's per-entry loop
+    (transforms.py:70-72) for every gamma of the golden streams and for exactly representable special cases."""
+    from graphite_amd import transforms as T
+    g = np.load(os.path.join(GOLD, "xforms.npz"))
+    gammas = {1.0, 2.0, 0.5, 3.0, 1.0 / 3.0, 1.5, 2.5, 3.5, 1.0 / 3.5}
+    for k in g.files:
+        a = g[k]
+        if a.ndim == 2 and a.shape[1] >= 3:
+            gammas.update(float(x) for x in a[:, 2])
+    assert len(gammas) > 500
+    for gm in gammas:
+        assert np.array_equal(T.gamma_table(gm), T._gamma_table_scalar(gm)), gm
