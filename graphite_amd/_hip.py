@@ -29,6 +29,7 @@ SIGNATURES = {
     "gr_last_error": (C.c_char_p, [_vp]),
     "gr_ctx_set_chunk": (_i, [_vp, _i]),
     "gr_ctx_workspace_bytes": (_i64, [_vp]),
+    "gr_ctx_set_workspace_limit": (_i, [_vp, _i64]),
     "gr_profile_enable": (_i, [_vp, _i]),
     "gr_profile_reset": (_i, [_vp]),
     "gr_profile_read": (_i, [_vp, _i, _vp]),
@@ -114,6 +115,10 @@ def ctx():
 
 def set_chunk(images_per_chunk):
     _check(ctx(), load_library().gr_ctx_set_chunk(ctx(), int(images_per_chunk)), "gr_ctx_set_chunk")
+
+
+def set_workspace_limit(nbytes):
+    _check(ctx(), load_library().gr_ctx_set_workspace_limit(ctx(), int(nbytes)), "gr_ctx_set_workspace_limit")
 
 
 def workspace_bytes():

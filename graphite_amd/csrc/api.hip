@@ -152,6 +152,23 @@ extern "C" int gr_ctx_set_chunk(gr_ctx* ctx, int n) {
     return GR_OK;
 }
 extern "C" int64_t gr_ctx_workspace_bytes(const gr_ctx* ctx) { return ctx ? (int64_t)ctx->ws_bytes : 0; }
+extern "C" int gr_ctx_set_workspace_limit(gr_ctx* ctx, int64_t bytes) {
+    if (!ctx) return GR_EINVAL;
+    if (bytes < ((int64_t)64 << 20)) return gr_fail(ctx, GR_EINVAL, "workspace limit must be at least 64 MiB");
+    ctx->ws_limit = (size_t)bytes;
+    return GR_OK;
+}
+// Images per classifier chunk for this model: the context's chunk, capped so that the classifier's scratch stays under
+// the workspace limit (GTSRBNet keeps 176 KB per image, WideResNet-34-10 3.3 MB: 8192 images of it would be 27 GB).
+static int chunk_for(const gr_ctx* ctx, const gr_model* m, int64_t want) {
+    const size_t per = net_workspace_bytes(m, 1024) / 1024 + 1;
+    int64_t cap = (int64_t)(ctx->ws_limit / per);
+    if (cap < 64) cap = 64;
+    int64_t c = ctx->chunk;
+    if (c > cap) c = cap;
+    if (c > want) c = want;
+    return (int)c;
+}
 
 // ---------------------------------------------------------------------------------------------
 // transform table
@@ -331,7 +348,7 @@ extern "C" int gr_model_forward(gr_ctx* ctx, gr_model* m, const float* x, int N,
     if (!m || !x || !logits || N < 0) return gr_fail(ctx, GR_EINVAL, "gr_model_forward: bad arguments");
     hipStream_t st = (hipStream_t)stream;
     const int ncls = gr_model_num_classes(m);
-    int chunk = ctx->chunk < N ? ctx->chunk : N;
+    int chunk = chunk_for(ctx, m, N);
     if (chunk <= 0) return GR_OK;
     size_t wsb = net_workspace_bytes(m, chunk);
     int rc = gr_ws_reserve(ctx, wsb, stream);
@@ -348,7 +365,7 @@ extern "C" int gr_model_predict(gr_ctx* ctx, gr_model* m, const float* x, int N,
     if (!m || !x || !preds || N < 0) return gr_fail(ctx, GR_EINVAL, "gr_model_predict: bad arguments");
     hipStream_t st = (hipStream_t)stream;
     const int ncls = gr_model_num_classes(m);
-    int chunk = ctx->chunk < N ? ctx->chunk : N;
+    int chunk = chunk_for(ctx, m, N);
     if (chunk <= 0) return GR_OK;
     size_t lg_bytes = gr_align((size_t)chunk * ncls * sizeof(float));
     size_t wsb = net_workspace_bytes(m, chunk);
@@ -398,7 +415,7 @@ extern "C" int gr_tr_hits(gr_ctx* ctx, gr_model* m, const float* img, int H, int
     if (C > 0) GR_HIP(ctx, hipMemsetAsync(hits, 0, sizeof(int32_t) * C, st));
     if (img_count == 0) return GR_OK;
     const int ncls = gr_model_num_classes(m);
-    const int chunk = (int)(ctx->chunk < img_count ? ctx->chunk : img_count);
+    const int chunk = chunk_for(ctx, m, img_count);
     // workspace: composites of the candidates one chunk can touch | chunk logits | net scratch.  The warp kernel writes
     // the classifier's NHWC4 input (GTSRBNet: after conv1_1 + ReLU) straight into the net scratch: no CHW image buffer,
     // no layout-change kernel in between.

@@ -17,6 +17,7 @@ struct gr_ctx {
     char* ws = nullptr;          // device workspace, grown on demand
     size_t ws_bytes = 0;
     int chunk = 8192;            // images per classifier chunk in gr_tr_hits
+    size_t ws_limit = (size_t)8 << 30;   // the classifier scratch of one chunk stays under this (gr_ctx_set_workspace_limit)
     char* static_scratch = nullptr;   // this device's copy of api.hip's file-scope `scratch` array (gr_ctx_create)
     bool prof = false;
     std::vector<ProfEntry> prof_entries;

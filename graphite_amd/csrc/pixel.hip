@@ -68,6 +68,11 @@ __global__ void k_resize(const float* __restrict__ src, int C, int sh, int sw, f
     const float* p = src + (size_t)c * sh * sw;
     float v;
     if (sh == dh && sw == dw) v = p[y * sw + x];
+    else if (sh == 2 * dh && sw == 2 * dw) {      // cv::resize's INTER_AREA fast path for an exact 2x2 reduction
+        const float* q = p + (2 * y) * sw + 2 * x;
+        v = (((0.f + q[0]) + q[1]) + q[sw]) + q[sw + 1];
+        v = v * 0.25f;
+    }
     else v = bilerp(p, sw, tap_h(x, sw, sx), tap_v(y, sh, sy));
     if (clamp) v = clamp01(v);
     if (normalize) v = v - 0.5f;
@@ -284,6 +289,7 @@ __global__ __launch_bounds__(256) void k_warp_net_any(const float* __restrict__ 
     const float4* att = reinterpret_cast<const float4*>(att_all) + ((size_t)cand * nslots + s_par[2]) * pl;
     const double scx = 1.0 / ((double)net / (double)cw), scy = 1.0 / ((double)net / (double)ch);
     const bool same = (cw == net && ch == net);
+    const bool area2 = (cw == 2 * net && ch == 2 * net);
     float* o = out + (size_t)local * 3 * net * net;
     for (int p = tid; p < net * net; p += 256) {
         int oy = p / net, ox = p % net;
@@ -298,9 +304,13 @@ __global__ __launch_bounds__(256) void k_warp_net_any(const float* __restrict__ 
             warp_gamma_rgbx(att, s_Mi, bw0, tx.i0, ty.i1, H, W, s_lutf, g10);
             warp_gamma_rgbx(att, s_Mi, bw0, tx.i1, ty.i1, H, W, s_lutf, g11);
             for (int c = 0; c < 3; c++) {
-                float h0 = g00[c] * tx.w0 + g01[c] * tx.w1;
-                float h1 = g10[c] * tx.w0 + g11[c] * tx.w1;
-                r[c] = h0 * ty.w0 + h1 * ty.w1;
+                if (area2) {                      // exact 2x2 reduction: cv::resize's INTER_AREA fast path
+                    r[c] = ((((0.f + g00[c]) + g01[c]) + g10[c]) + g11[c]) * 0.25f;
+                } else {
+                    float h0 = g00[c] * tx.w0 + g01[c] * tx.w1;
+                    float h1 = g10[c] * tx.w0 + g11[c] * tx.w1;
+                    r[c] = h0 * ty.w0 + h1 * ty.w1;
+                }
             }
         }
         for (int c = 0; c < 3; c++) {
@@ -346,6 +356,7 @@ __global__ __launch_bounds__(256) void k_warp_net32(const float* __restrict__ at
     const int tid = threadIdx.x;
     const int cw = x->crop_x, ch = x->crop_y, bw0 = x->bw0, sep = x->sep;
     const bool same = (cw == net && ch == net);
+    const bool area2 = (cw == 2 * net && ch == 2 * net);      // exact 2x2 reduction (crop 64): taps 2o, 2o+1 as bilinear gives
     const double scx = 1.0 / ((double)net / (double)cw), scy = 1.0 / ((double)net / (double)ch);
     s_lutf[tid] = clamp01((float)((double)x->lut[tid] / 255.0));
     if (tid < 9) s_Mi[tid] = x->Mi[tid];
@@ -411,6 +422,7 @@ __global__ __launch_bounds__(256) void k_warp_net32(const float* __restrict__ at
         for (int c = 0; c < 3; c++) {
             float r;
             if (same) r = g[0][0][c];
+            else if (area2) r = ((((0.f + g[0][0][c]) + g[0][1][c]) + g[1][0][c]) + g[1][1][c]) * 0.25f;   // INTER_AREA fast path
             else {
                 const float h0 = g[0][0][c] * tx.w0 + g[0][1][c] * tx.w1;
                 const float h1 = g[1][0][c] * tx.w0 + g[1][1][c] * tx.w1;

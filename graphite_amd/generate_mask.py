@@ -33,6 +33,39 @@ FINE_WINDOW = 32          # largest speculative window (candidates per launch) i
 FINE_WINDOW_MIN = 4       # the window doubles after a fully consumed launch and halves after a mis-speculation
 
 
+def _storage_from_bytes(b):
+    """Stand-in for torch.storage._load_from_bytes (what a pickled tensor's storage names): the real one is
+    torch.load(..., weights_only=False), i.e. a second, unrestricted unpickler.  This one can only build storages."""
+    import io
+    return torch.load(io.BytesIO(b), weights_only=True)
+
+
+class _HeatmapUnpickler(pickle.Unpickler):
+    """Loader for the heatmap cache in the reference's format: pickle.dump of {'heatmap_query_ct', 'patches', 'indices',
+    'order'} = an int, CPU torch tensors, tuples, one numpy index array (generate_mask.py:72-79).  The reference reloads it
+    with plain pickle.load (:82-83); a pickle is a program, so here only the constructors those types need can be
+    resolved, the tensor storages go through torch's weights-only loader, and any other global in the file raises
+    instead of running."""
+    _PLAIN = {("collections", "OrderedDict"), ("torch._utils", "_rebuild_tensor_v2"),
+              ("numpy.core.multiarray", "_reconstruct"), ("numpy._core.multiarray", "_reconstruct"),
+              ("numpy", "ndarray"), ("numpy", "dtype")}
+
+    def find_class(self, module, name):
+        if (module, name) == ("torch.storage", "_load_from_bytes"):
+            return _storage_from_bytes
+        if (module, name) in self._PLAIN:
+            return super().find_class(module, name)
+        raise pickle.UnpicklingError("heatmap file refers to %s.%s, which a heatmap cache never contains" % (module, name))
+
+
+def load_heatmap(path):
+    with open(path, 'rb') as f:
+        heatmap = _HeatmapUnpickler(f).load()
+    if not isinstance(heatmap, dict) or not {'heatmap_query_ct', 'patches', 'indices', 'order'} <= set(heatmap):
+        raise ValueError("not a heatmap cache: " + str(path))
+    return heatmap
+
+
 def _load_scoremod(scorefile):
     name = scorefile.strip('.py')          # the reference's (character-set) strip, generate_mask.py:32
     importlib.invalidate_caches()
@@ -80,8 +113,7 @@ def generate_mask(model, img_v_small, img_v, lbl_v, mask, img_t_small, img_t, lb
                 pickle.dump({'heatmap_query_ct': heatmap_query_ct, 'patches': patches, 'indices': indices,
                              'order': order}, f)
     else:
-        with open(heatmap_file, 'rb') as f:
-            heatmap = pickle.load(f)
+        heatmap = load_heatmap(heatmap_file)
         heatmap_query_ct = heatmap['heatmap_query_ct']
         patches, indices, order = heatmap['patches'], heatmap['indices'], heatmap['order']
         query_count += heatmap_query_ct

@@ -61,6 +61,11 @@ const char* gr_last_error(const gr_ctx* ctx);
 int gr_ctx_set_chunk(gr_ctx* ctx, int images_per_chunk);
 /* Bytes of device workspace currently held. */
 int64_t gr_ctx_workspace_bytes(const gr_ctx* ctx);
+/* Upper bound for the classifier scratch of one chunk (default 8 GiB): the chunk of a call is
+ * min(gr_ctx_set_chunk's value, limit / scratch bytes per image of the model) -- GTSRBNet keeps 176 KB per image,
+ * WideResNet-34-10 3.3 MB, so its chunks are 2,500 images at the default.  The workspace is grow-only and is returned
+ * by gr_ctx_destroy. */
+int gr_ctx_set_workspace_limit(gr_ctx* ctx, int64_t bytes);
 
 /* ---- measurement (no counterpart in the reference, which only prints time.time() deltas,
  * boost.py:27,55; coarse_reduction.py:76).  With profiling on, every kernel launch the library

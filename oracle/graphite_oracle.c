@@ -31,6 +31,10 @@ static inline int clipi(int x, int a, int b) { return x >= a ? (x < b ? x : b - 
  *   horizontal: s<0 -> (s,f)=(0,0); s>=sw-1 -> (s,f)=(sw-1,0); taps S[s]*(1-f) + S[s+1]*f
  *   vertical:   rows clip(s), clip(s+1); weights (1-f, f) from the UNclamped f
  *   horizontal pass first (per source row), then vertical; equal sizes -> copy.
+ *   EXACTLY 2x down in both directions: cv::resize switches INTER_LINEAR to the INTER_AREA fast path
+ *   (resize.cpp: "in case of scale_x && scale_y is equal to 2 INTER_AREA (fast) also is equal to INTER_LINEAR");
+ *   for 3-channel float images that is the scalar ResizeAreaFast loop: sum = ((S00 + S01) + S10) + S11, D = sum * 0.25f
+ *   (the same taps as the bilinear path, whose weights are all 0.5, in a different summation order: <= 1 ulp apart).
  * ------------------------------------------------------------------------------------------ */
 typedef struct { int i0, i1; float w0, w1; } tap_t;
 
@@ -57,6 +61,18 @@ static void resize_taps(int ssize, int dsize, int horizontal, tap_t* t) {
 
 static void resize_plane(const float* S, int sh, int sw, float* D, int dh, int dw, const tap_t* tx, const tap_t* ty) {
     if (sh == dh && sw == dw) { memcpy(D, S, sizeof(float) * (size_t)sh * sw); return; }
+    if (sh == 2 * dh && sw == 2 * dw) {                     /* INTER_AREA fast path, scale 2 x 2 */
+        for (int dy = 0; dy < dh; dy++) {
+            const float* r0 = S + (size_t)(2 * dy) * sw;
+            const float* r1 = r0 + sw;
+            for (int dx = 0; dx < dw; dx++) {
+                float sum = 0.f;
+                sum += r0[2 * dx] + r0[2 * dx + 1] + r1[2 * dx] + r1[2 * dx + 1];
+                D[(size_t)dy * dw + dx] = sum * 0.25f;
+            }
+        }
+        return;
+    }
     for (int dy = 0; dy < dh; dy++) {
         const float* r0 = S + (size_t)ty[dy].i0 * sw;
         const float* r1 = S + (size_t)ty[dy].i1 * sw;

@@ -129,3 +129,52 @@ def test_parsearguments_defaults_and_derived():
     a = parsearguments.getarguments("-v 14 -t 27 --tr_lo 0.65 --tr_hi 0.85 -b 100 -m 100 --coarse_mode=binary --junk 1".split())
     assert a.lbl_t == 27 and abs(a.coarse_error - 0.15) < 1e-12 and abs(a.reduce_error - 0.35) < 1e-12
     assert a.img_v == 'inputs/GTSRB/images/14.png' and a.mask == 'inputs/GTSRB/Hulls/14.png'
+
+
+def test_heatmap_cache_round_trip_and_restricted_loader(scene, oracle, tmp_path):
+    """A heatmap cache written through heatmap_out_path (the reference's pickle layout, generate_mask.py:72-79) reloads
+    through heatmap_file with identical downstream decisions and no heatmap evaluations; the loader resolves only the
+    constructors such a file needs, so a pickle that names anything else is refused instead of executed."""
+    import io
+    import pickle
+    row = [r for r in ROWS if r["kind"] == "generate_mask"][0]
+    args = parsearguments.getarguments(["--coarse_mode", row["coarse_mode"]])
+
+    def run(**kw):
+        fake = FakeTR(row["T"], scene["obj"], scene["ref_dir"], row["sharp"], row["mid"])
+        ev = FakeEvaluator(fake, oracle)
+        np.random.seed(42); torch.manual_seed(42); random.seed(42)
+        out = ggm.generate_mask(None, scene["vic_s"], scene["vic"], 14, scene["hull"].clone(), scene["tar_s"], scene["tar"], 1, PT,
+                                "score.py", row["heatmap"], 1 - row["tr_hi"], 1 - row["tr_lo"], num_xforms=row["T"], net_size=32,
+                                model_type='GTSRB', patch_size=4, max_mask_size=row["max_mask_size"], _evaluator=ev, _args=args, **kw)
+        return out, ev
+
+    path = str(tmp_path / "heatmap.pkl")
+    (att1, q1, mask1, nbits1, tr1), ev1 = run(heatmap_out_path=path)
+    with open(path, "rb") as f:
+        plain = pickle.load(f)                              # our own file: the reference's keys and types
+    assert set(plain) == {"heatmap_query_ct", "patches", "indices", "order"} and isinstance(plain["patches"][0], torch.Tensor)
+    (att2, q2, mask2, nbits2, tr2), ev2 = run(heatmap_file=path)
+    assert int(q1) == int(q2) == row["query_count"] and nbits1 == nbits2 and tr1 == tr2
+    assert torch.equal(mask1, mask2) and torch.equal(att1, att2)
+    assert ev2.evaluated == ev1.evaluated - len(plain["patches"])          # the heatmap itself was not re-evaluated
+
+    class Evil:
+        def __reduce__(self):
+            return (os.system, ("echo pwned > %s" % (tmp_path / "pwned"),))
+
+    for payload in (pickle.dumps({"heatmap_query_ct": 0, "patches": [Evil()], "indices": [], "order": []}),
+                    pickle.dumps(Evil())):
+        bad = tmp_path / "evil.pkl"
+        bad.write_bytes(payload)
+        with pytest.raises(pickle.UnpicklingError, match="never contains"):
+            ggm.load_heatmap(str(bad))
+    # a tensor whose storage bytes are themselves a hostile pickle: the storage loader is weights-only
+    inner = io.BytesIO()
+    pickle.dump(Evil(), inner)
+    with pytest.raises(Exception):
+        ggm._storage_from_bytes(inner.getvalue())
+    assert not (tmp_path / "pwned").exists()
+    (tmp_path / "notaheatmap.pkl").write_bytes(pickle.dumps({"a": 1}))
+    with pytest.raises(ValueError, match="not a heatmap"):
+        ggm.load_heatmap(str(tmp_path / "notaheatmap.pkl"))
