@@ -40,6 +40,9 @@ SIGNATURES = {
     "gr_add_noise": (_i, [_vp, _vp, _i, _i, _vp, _vp, _i, _i, _f, _i, _vp, _vp, _vp, _vp]),
     "gr_warp_perspective": (_i, [_vp, _vp, _i, _i, _vp, _i, _i, _vp, _vp]),
     "gr_transform_composited": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp, _i, _i, _vp, _vp]),
+    "gr_net_size": (_i, [_i, _i, _i, C.POINTER(_i), C.POINTER(_i)]),
+    "gr_transform_composited_var": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp, _i, _vp, _i64, _vp]),
+    "gr_warp_batch_var": (_i, [_vp, _vp, _i, _i, _vp, _vp, _i, _i, _i, _vp, _f, _i, _vp, _i64, _vp]),
     "gr_transform_composited_static": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp, _i, _i, _vp, _vp]),
     "gr_warp_batch": (_i, [_vp, _vp, _i, _i, _vp, _vp, _i, _i, _i, _vp, _f, _i, _i, _vp, _vp]),
     "gr_model_load_gtsrb": (_i, [_vp, _vp, _vp, _i, C.POINTER(_vp)]),
@@ -209,10 +212,58 @@ def resize_linear(src, dh, dw):
     return d.cpu().numpy()
 
 
+def net_size(crop_x, crop_y, net):
+    """(nx, ny) of convert2Network's output for a crop_x x crop_y image (gr_net_size)."""
+    nx, ny = _i(), _i()
+    rc = load_library().gr_net_size(int(crop_x), int(crop_y), int(net), C.byref(nx), C.byref(ny))
+    if rc != 0:
+        raise GraphiteHipError("gr_net_size: bad arguments")
+    return nx.value, ny.value
+
+
+def _split_var(out, tab, net):
+    """[N, stride] device buffer -> list of CPU arrays [3, ny_t, nx_t] (one per image, transform = index % T)."""
+    sizes = [net_size(int(t["crop_x"]), int(t["crop_y"]), net) for t in tab]
+    host = out.cpu().numpy()
+    T = len(tab)
+    return [host[i, :3 * sizes[i % T][0] * sizes[i % T][1]].reshape(3, sizes[i % T][1], sizes[i % T][0]).copy()
+            for i in range(host.shape[0])]
+
+
+def _var_stride(tab, net):
+    return max(3 * nx * ny for nx, ny in (net_size(int(t["crop_x"]), int(t["crop_y"]), net) for t in tab))
+
+
+def transform_composited_var(img, mask_lg, pert, tab, net):
+    """apply_transformation's net_size != 32 branch for every transform of `tab`: list of [3, ny_t, nx_t] arrays."""
+    i, m, p = to_dev(img), to_dev(mask_lg), to_dev(pert)
+    _, H, W = i.shape
+    xf = xform_table(tab)
+    stride = _var_stride(xf.host, net)
+    out = torch.zeros((xf.T, stride), device=i.device, dtype=torch.float32)
+    _check(ctx(), load_library().gr_transform_composited_var(ctx(), _p(i), _p(m), _p(p), H, W, xf._h, net, _p(out), stride,
+                                                             _stream()), "gr_transform_composited_var")
+    return _split_var(out, xf.host, net)
+
+
+def warp_batch_var(img, masks, thetas, tab, lbd, net):
+    """get_transformed_images' net_size != 32 branch for C candidates: list (c-major) of [3, ny_t, nx_t] arrays."""
+    i, m, t = to_dev(img), to_dev(masks), to_dev(thetas)
+    _, H, W = i.shape
+    Cn, _, nh, nw = m.shape
+    xf = xform_table(tab)
+    stride = _var_stride(xf.host, net)
+    out = torch.zeros((Cn * xf.T, stride), device=i.device, dtype=torch.float32)
+    _check(ctx(), load_library().gr_warp_batch_var(ctx(), _p(i), H, W, _p(m), _p(t), Cn, nh, nw, xf._h, lbd, net, _p(out),
+                                                   stride, _stream()), "gr_warp_batch_var")
+    return _split_var(out, xf.host, net)
+
+
 def convert_to_network(src, net, normalize):
     s = to_dev(src)
     _, sh, sw = s.shape
-    d = torch.empty((3, net, net), device=s.device, dtype=torch.float32)
+    nx, ny = net_size(sw, sh, net)
+    d = torch.empty((3, ny, nx), device=s.device, dtype=torch.float32)
     _check(ctx(), load_library().gr_convert_to_network(ctx(), _p(s), sh, sw, _p(d), net, int(normalize), _stream()),
            "gr_convert_to_network")
     return d.cpu().numpy()

@@ -220,6 +220,7 @@ extern "C" int gr_xforms_create(gr_ctx* ctx, const gr_xform* h, int T, gr_xforms
         }
         invert3x3(h[t].M, d[t].Mi);
         d[t].crop_x = h[t].crop_x; d[t].crop_y = h[t].crop_y;
+        x->crop.push_back({h[t].crop_x, h[t].crop_y});
         d[t].slot = slot_of[h[t].blur];
         d[t].bw0 = warp_block_w(h[t].crop_x, h[t].crop_y);
         d[t].sep = (d[t].Mi[1] == 0.0 && d[t].Mi[7] == 0.0) ? 1 : 0;
@@ -254,6 +255,11 @@ extern "C" int gr_resize_linear(gr_ctx* ctx, const float* src, int C, int sh, in
 extern "C" int gr_convert_to_network(gr_ctx* ctx, const float* src, int sh, int sw, float* dst, int net, int normalize, void* stream) {
     NEED_CTX();
     if (!src || !dst || sh <= 0 || sw <= 0 || net <= 0) return gr_fail(ctx, GR_EINVAL, "gr_convert_to_network: bad arguments");
+    if (net != 32) {                                   // transforms.py:31-45: short side -> net, aspect kept, clamp only
+        int nx, ny;
+        px_net_size(sw, sh, net, &nx, &ny);
+        return px_resize(ctx, src, 3, sh, sw, dst, ny, nx, 1, 0, (hipStream_t)stream);
+    }
     return px_resize(ctx, src, 3, sh, sw, dst, net, net, 1, normalize, (hipStream_t)stream);
 }
 extern "C" int gr_add_noise(gr_ctx* ctx, const float* img, int H, int W, const float* mask, const float* theta, int nh, int nw,
@@ -290,6 +296,72 @@ extern "C" int gr_transform_composited(gr_ctx* ctx, const float* img, const floa
     float* att = (float*)ctx->ws;
     if ((rc = px_composite_from_pert(ctx, img, mask_lg, pert, H, W, xf, att, st))) return rc;
     return px_warp_net(ctx, att, H, W, xf, 0, xf->T, 0, normalize, net, out, st);
+}
+
+extern "C" int gr_net_size(int crop_x, int crop_y, int net_size, int* nx, int* ny) {
+    if (!nx || !ny || crop_x <= 0 || crop_y <= 0 || net_size <= 0) return GR_EINVAL;
+    if (net_size == 32) { *nx = *ny = 32; return GR_OK; }          // transforms.py:19-29: always 32 x 32
+    px_net_size(crop_x, crop_y, net_size, nx, ny);
+    return GR_OK;
+}
+
+// largest [3, ny, nx] image any transform of the table produces at this net_size, in floats
+static int64_t var_image_floats(const gr_xforms* xf, int net_size) {
+    int64_t mx = 0;
+    for (int t = 0; t < xf->T; t++) {
+        int nx, ny;
+        px_net_size(xf->crop[t][0], xf->crop[t][1], net_size, &nx, &ny);
+        if ((int64_t)3 * nx * ny > mx) mx = (int64_t)3 * nx * ny;
+    }
+    return mx;
+}
+
+extern "C" int gr_transform_composited_var(gr_ctx* ctx, const float* img, const float* mask_lg, const float* pert, int H, int W,
+                                           const gr_xforms* xf, int net_size, float* out, int64_t out_stride, void* stream) {
+    NEED_CTX();
+    if (!img || !mask_lg || !pert || !out) return gr_fail(ctx, GR_EINVAL, "gr_transform_composited_var: null pointer");
+    int rc = check_frame(ctx, H, W, H, W, net_size, xf);
+    if (rc) return rc;
+    if (net_size == 32) return gr_fail(ctx, GR_EINVAL, "net_size 32 is the fixed-size branch: use gr_transform_composited");
+    if (out_stride < var_image_floats(xf, net_size)) return gr_fail(ctx, GR_EINVAL, "gr_transform_composited_var: out_stride too small");
+    hipStream_t st = (hipStream_t)stream;
+    size_t att_bytes = gr_align((size_t)xf->nslots * H * W * 16);
+    if ((rc = gr_ws_reserve(ctx, att_bytes, stream))) return rc;
+    float* att = (float*)ctx->ws;
+    if ((rc = px_composite_from_pert(ctx, img, mask_lg, pert, H, W, xf, att, st))) return rc;
+    return px_warp_net(ctx, att, H, W, xf, 0, xf->T, 0, 0, net_size, out, st, GR_OUT_CHW, nullptr, out_stride);
+}
+
+extern "C" int gr_warp_batch_var(gr_ctx* ctx, const float* img, int H, int W, const float* masks, const float* thetas, int C,
+                                 int nh, int nw, const gr_xforms* xf, float lbd, int net_size, float* out, int64_t out_stride,
+                                 void* stream) {
+    NEED_CTX();
+    if (C == 0) return GR_OK;
+    if (!img || !masks || !thetas || !out || C < 0) return gr_fail(ctx, GR_EINVAL, "gr_warp_batch_var: bad arguments");
+    int rc = check_frame(ctx, H, W, nh, nw, net_size, xf);
+    if (rc) return rc;
+    if (net_size == 32) return gr_fail(ctx, GR_EINVAL, "net_size 32 is the fixed-size branch: use gr_warp_batch");
+    if (out_stride < var_image_floats(xf, net_size)) return gr_fail(ctx, GR_EINVAL, "gr_warp_batch_var: out_stride too small");
+    hipStream_t st = (hipStream_t)stream;
+    const size_t per_cand = (size_t)xf->nslots * H * W * 16;
+    int cpass = (int)(((size_t)2 << 30) / per_cand);
+    if (cpass < 1) cpass = 1;
+    if (cpass > C) cpass = C;
+    if ((rc = gr_ws_reserve(ctx, gr_align(per_cand * cpass), stream))) return rc;
+    float* att = (float*)ctx->ws;
+    const int T = xf->T;
+    for (int c0 = 0; c0 < C; c0 += cpass) {
+        int nc = C - c0 < cpass ? C - c0 : cpass;
+        if ((rc = px_composite(ctx, img, H, W, masks + (size_t)c0 * 3 * nh * nw, thetas + (size_t)c0 * 3 * nh * nw, nc, nh, nw,
+                               lbd, xf, att, st))) return rc;
+        long long nimg = (long long)nc * T;
+        for (long long o = 0; o < nimg; o += (1 << 30)) {
+            int cnt = (int)(nimg - o < (1 << 30) ? nimg - o : (1 << 30));
+            if ((rc = px_warp_net(ctx, att, H, W, xf, (int64_t)c0 * T + o, cnt, c0, 0, net_size,
+                                  out + ((size_t)c0 * T + o) * (size_t)out_stride, st, GR_OUT_CHW, nullptr, out_stride))) return rc;
+        }
+    }
+    return GR_OK;
 }
 
 // gr_transform_composited without any allocation: the composites live in this device's copy of `scratch`.

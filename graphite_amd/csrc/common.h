@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <array>
 #include <string>
 #include <vector>
 #include "graphite_hip.h"
@@ -51,6 +52,7 @@ struct gr_xforms {
     XformDev* dev = nullptr;
     int nslots = 0;              // number of distinct blur kernels in the table
     int slot_blur[4] = {0, 0, 0, 0};   // blur kernel size of each slot
+    std::vector<std::array<int, 2>> crop;   // host copy of (crop_x, crop_y) per transform
 };
 
 int gr_fail(gr_ctx* ctx, int code, const char* fmt, ...);
@@ -82,7 +84,11 @@ int px_composite_from_pert(gr_ctx*, const float* img, const float* mask_lg, cons
 // GR_OUT_NHWC4_C11 (net == 32 only): the same after GTSRBNet's conv1_1 (1x1, c11 = 9 weights + 3 biases, dev) + ReLU.
 enum { GR_OUT_CHW = 0, GR_OUT_NHWC4 = 1, GR_OUT_NHWC4_C11 = 2 };
 int px_warp_net(gr_ctx*, const float* att, int H, int W, const gr_xforms* xf, int64_t n_begin, int count, int cand0,
-                int normalize, int net, float* out, hipStream_t, int out_mode = GR_OUT_CHW, const float* c11 = nullptr);
+                int normalize, int net, float* out, hipStream_t, int out_mode = GR_OUT_CHW, const float* c11 = nullptr,
+                int64_t var_stride = 0);
+// var_stride > 0: the net_size != 32 branch of convert2Network (transforms.py:31-45): image i is written at
+// out + i * var_stride as [3, ny, nx] with (nx, ny) = px_net_size(crop_x, crop_y, net); clamp only, no normalisation
+void px_net_size(int crop_x, int crop_y, int net_size, int* nx, int* ny);
 
 // ---- nets.hip ----
 struct gr_model;

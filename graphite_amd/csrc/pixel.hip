@@ -267,10 +267,21 @@ __device__ __forceinline__ int warp_local_index(int count, int xcd_map) {
     return (blockIdx.x & 7) * per + (blockIdx.x >> 3);   // >= count for the padding workgroups of the rounded-up grid
 }
 
-// Generic network size (net x net, CHW output): every warped pixel runs the full coordinate computation.
+// convert2Network's size rule for net_size != 32 (transforms.py:35-40, the ALPR branch): the SHORT side of the warped
+// image becomes net_size, the long side int(round(net_size / short * long)) -- Python float arithmetic, round half even.
+__host__ __device__ inline void net_size_rule(int cw, int ch, int net_size, int* nx, int* ny) {
+    if (ch > cw) { *nx = net_size; *ny = (int)rint((double)net_size / (double)cw * (double)ch); }
+    else { *ny = net_size; *nx = (int)rint((double)net_size / (double)ch * (double)cw); }
+}
+
+// Generic network size, CHW output: every warped pixel runs the full coordinate computation.
+// var == 0: net x net output, `normalize` as given (the net_size == 32 branch of convert2Network for any net).
+// var == 1: the net_size != 32 branch: per transform ny x nx by net_size_rule, clamp only (that branch never normalises);
+//           image `local` is written at out + local * out_stride as [3, ny, nx].
 __global__ __launch_bounds__(256) void k_warp_net_any(const float* __restrict__ att_all, int H, int W, int nslots,
                                                       const XformDev* __restrict__ xf, int T, long long n_begin, int cand0,
-                                                      int normalize, int net, int count, int xcd_map, float* __restrict__ out) {
+                                                      int normalize, int net, int var, long long out_stride, int count,
+                                                      int xcd_map, float* __restrict__ out) {
     __shared__ double s_Mi[9];
     __shared__ float s_lutf[256];
     __shared__ int s_par[4];
@@ -287,12 +298,15 @@ __global__ __launch_bounds__(256) void k_warp_net_any(const float* __restrict__ 
     const int cw = s_par[0], ch = s_par[1], bw0 = s_par[3];
     const size_t pl = (size_t)H * W;
     const float4* att = reinterpret_cast<const float4*>(att_all) + ((size_t)cand * nslots + s_par[2]) * pl;
-    const double scx = 1.0 / ((double)net / (double)cw), scy = 1.0 / ((double)net / (double)ch);
-    const bool same = (cw == net && ch == net);
-    const bool area2 = (cw == 2 * net && ch == 2 * net);
-    float* o = out + (size_t)local * 3 * net * net;
-    for (int p = tid; p < net * net; p += 256) {
-        int oy = p / net, ox = p % net;
+    int nx = net, ny = net;
+    if (var) { net_size_rule(cw, ch, net, &nx, &ny); normalize = 0; }
+    const double scx = 1.0 / ((double)nx / (double)cw), scy = 1.0 / ((double)ny / (double)ch);
+    const bool same = (cw == nx && ch == ny);
+    const bool area2 = (cw == 2 * nx && ch == 2 * ny);
+    float* o = out + (size_t)local * (size_t)out_stride;
+    const int npx = nx * ny;
+    for (int p = tid; p < npx; p += 256) {
+        int oy = p / nx, ox = p % nx;
         float r[3];
         if (same) {
             warp_gamma_rgbx(att, s_Mi, bw0, ox, oy, H, W, s_lutf, r);
@@ -315,7 +329,7 @@ __global__ __launch_bounds__(256) void k_warp_net_any(const float* __restrict__ 
         }
         for (int c = 0; c < 3; c++) {
             float v = clamp01(r[c]);
-            o[c * net * net + p] = normalize ? v - 0.5f : v;
+            o[c * npx + p] = normalize ? v - 0.5f : v;
         }
     }
 }
@@ -536,9 +550,12 @@ int px_composite_from_pert(gr_ctx* ctx, const float* img, const float* mask_lg, 
     return GR_OK;
 }
 
+void px_net_size(int crop_x, int crop_y, int net_size, int* nx, int* ny) { net_size_rule(crop_x, crop_y, net_size, nx, ny); }
+
 int px_warp_net(gr_ctx* ctx, const float* att, int H, int W, const gr_xforms* xf, int64_t n_begin, int count, int cand0,
-                int normalize, int net, float* out, hipStream_t st, int out_mode, const float* c11) {
+                int normalize, int net, float* out, hipStream_t st, int out_mode, const float* c11, int64_t var_stride) {
     if (count <= 0) return GR_OK;
+    if (var_stride > 0 && out_mode != GR_OUT_CHW) return gr_fail(ctx, GR_EINVAL, "px_warp_net: variable-size output is CHW only");
     if (out_mode != GR_OUT_CHW && net != 32) return gr_fail(ctx, GR_EINVAL, "px_warp_net: NHWC4 output needs net == 32");
     if (out_mode == GR_OUT_NHWC4_C11 && !c11) return gr_fail(ctx, GR_EINVAL, "px_warp_net: conv1_1 parameters missing");
     // algorithmic bytes: 12 B/px written per image + 336 B of transform descriptor read
@@ -547,9 +564,10 @@ int px_warp_net(gr_ctx* ctx, const float* att, int H, int W, const gr_xforms* xf
     if (xcd_map < 0) { const char* e = getenv("GRAPHITE_WARP_XCD"); xcd_map = (e && e[0] == '0') ? 0 : 1; }
     const int use_map = (xcd_map && count >= 64) ? 1 : 0;
     const int grid = use_map ? 8 * ((count + 7) / 8) : count;
-    if (net != 32) {
+    if (net != 32 || var_stride > 0) {
         hipLaunchKernelGGL(k_warp_net_any, dim3(grid), dim3(256), 0, st, att, H, W, xf->nslots, xf->dev, xf->T,
-                           (long long)n_begin, cand0, normalize, net, count, use_map, out);
+                           (long long)n_begin, cand0, normalize, net, var_stride > 0 ? 1 : 0,
+                           (long long)(var_stride > 0 ? var_stride : (int64_t)3 * net * net), count, use_map, out);
     } else {
 #define WN(M) hipLaunchKernelGGL(k_warp_net32<M>, dim3(grid), dim3(256), 0, st, att, H, W, xf->nslots, xf->dev, xf->T, \
                                  (long long)n_begin, cand0, normalize, count, use_map, c11, out)

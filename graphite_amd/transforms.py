@@ -141,15 +141,15 @@ def _chw(t):
 
 
 def convert2Network(img, is_torch=True, net_size=32, model_type='GTSRB'):
-    """Resize to 32x32 (bilinear, no anti-alias), clamp to [0,1], GTSRB: subtract 0.5.
+    """net_size == 32 (:19-29): resize to 32x32 (bilinear, no anti-alias), clamp to [0,1], GTSRB: subtract 0.5.
+    net_size != 32 (:31-45, the licence-plate branch): the short side becomes net_size, the aspect ratio is kept
+    (long side int(round(net_size / short * long))), clamp only.
     `img` is a CHW tensor (is_torch) or an HWC numpy array; returns a CHW CPU tensor."""
-    if net_size != 32:
-        raise NotImplementedError("only the net_size == 32 branch (GTSRB/CIFAR) is on this path")
     from . import _hip
     x = _chw(img) if is_torch else np.ascontiguousarray(np.transpose(np.asarray(img, np.float32), (2, 0, 1)))
-    y = _hip.convert_to_network(x, net_size, model_type == 'GTSRB')
+    y = _hip.convert_to_network(x, net_size, model_type == 'GTSRB' and net_size == 32)
     out = torch.from_numpy(y)
-    assert torch.max(out) <= (0.5 if model_type == 'GTSRB' else 1.0)
+    assert torch.max(out) <= (0.5 if (model_type == 'GTSRB' and net_size == 32) else 1.0)
     return out
 
 
@@ -165,32 +165,35 @@ def add_noise(image, mask, lbd, theta, return_pert_and_mask=False, clip=True):
 
 def apply_transformation(img, mask, pert, angle, dist, gamma, blur, crop_percent, crop_off_x, crop_off_y,
                          pt_file, net_size=32, obj_width=30, focal=3, nps=False, model_type='GTSRB'):
-    """One transform of an already-composited (img, mask_lg, pert) triple -> CHW [3,32,32] tensor."""
-    if net_size != 32:
-        raise NotImplementedError("only the net_size == 32 branch (GTSRB/CIFAR) is on this path")
+    """One transform of an already-composited (img, mask_lg, pert) triple -> CHW tensor: [3,32,32] for net_size 32,
+    [3,ny,nx] (short side net_size, clamp only) otherwise."""
     from . import _hip
     img_np, mask_np, pert_np = _chw(img), _chw(mask), _chw(pert)
     tab = build_xform_table([(angle, dist, gamma, blur, crop_percent, crop_off_x, crop_off_y, obj_width, focal, nps)],
                             img_np.shape[2], img_np.shape[1], pt_file)
+    if net_size != 32:
+        return torch.from_numpy(_hip.transform_composited_var(img_np, mask_np, pert_np, tab, net_size)[0])
     y = _hip.transform_composited(img_np, mask_np, pert_np, tab, net_size, model_type == 'GTSRB')
     return torch.from_numpy(y[0])
 
 
 def get_transformed_images(image, mask, transforms, lbd, theta, pt_file='inputs/GTSRB/Points/14.csv',
                            net_size=32, model_type='GTSRB'):
-    """List of len(transforms) CHW [3,32,32] CPU tensors (one with no transforms), as the reference returns.
+    """List of len(transforms) CHW CPU tensors (one with no transforms), as the reference returns: [3,32,32] for
+    net_size 32; for any other net_size [3,ny,nx] with the short side = net_size (frames of any aspect ratio).
 
     All transforms of the candidate are produced by one fused launch; callers that only
     need hit counts should use `graphite_amd.tr_hits`, which never leaves the GPU.
     """
-    if net_size != 32:
-        raise NotImplementedError("only the net_size == 32 branch (GTSRB/CIFAR) is on this path")
     from . import _hip
     img_np = _chw(image)
     if len(transforms) == 0:
         att = add_noise(image, mask, lbd, theta, True)[0]
         return [convert2Network(att, net_size=net_size, model_type=model_type)]
     tab = build_xform_table(transforms, img_np.shape[2], img_np.shape[1], pt_file)
+    if net_size != 32:          # :31-45: every transform has its own [3, ny, nx] (aspect of ITS crop), clamp only
+        return [torch.from_numpy(a) for a in _hip.warp_batch_var(img_np, _chw(mask)[None], _chw(theta)[None], tab,
+                                                                 float(lbd), net_size)]
     out = _hip.warp_batch(img_np, _chw(mask)[None], _chw(theta)[None], tab, float(lbd), model_type == 'GTSRB',
                           net_size)
     t = torch.from_numpy(out[0])

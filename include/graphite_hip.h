@@ -91,7 +91,10 @@ void gr_xforms_destroy(gr_xforms* xf);
 /* ---- pixel operators (all pointers dev) ----------------------------------------------------- */
 /* cv2.resize(src,(dw,dh)) INTER_LINEAR on C planes: transforms.py:23,148,151; boost.py:33,42. */
 int gr_resize_linear(gr_ctx* ctx, const float* src, int C, int sh, int sw, float* dst, int dh, int dw, void* stream);
-/* convert2Network, transforms.py:18-29: resize to net x net, clamp [0,1], minus 0.5 if normalize. */
+/* convert2Network.  net == 32 (transforms.py:18-29): resize to 32 x 32, clamp [0,1], minus 0.5 if normalize;
+ * dst = [3,32,32].  net != 32 (transforms.py:31-45, the licence-plate branch): the short side becomes net, the long side
+ * int(round(net / short * long)) (gr_net_size), clamp only -- `normalize` is ignored as that branch never normalises;
+ * dst = [3,ny,nx]. */
 int gr_convert_to_network(gr_ctx* ctx, const float* src, int sh, int sw, float* dst, int net, int normalize,
                           void* stream);
 /* add_noise, transforms.py:143-159.  comb / pert / mask_lg are [3,H,W] outputs, any may be NULL. */
@@ -105,6 +108,18 @@ int gr_warp_perspective(gr_ctx* ctx, const float* src, int H, int W, const doubl
  * (img, mask_lg, pert as returned by add_noise).  out = [T,3,net,net]. */
 int gr_transform_composited(gr_ctx* ctx, const float* img, const float* mask_lg, const float* pert, int H, int W,
                             const gr_xforms* xf, int normalize, int net, float* out, void* stream);
+/* Output size of convert2Network for a warped image of crop_x x crop_y (host helper, no GPU work): 32 x 32 for
+ * net_size == 32 (transforms.py:19-23), else transforms.py:35-40 in Python's float arithmetic (round half to even). */
+int gr_net_size(int crop_x, int crop_y, int net_size, int* nx, int* ny);
+/* The net_size != 32 branch (transforms.py:31-45 behind apply_transformation :77 / get_transformed_images :162-173) for
+ * frames of any aspect ratio (perspective_transform.py:39-44 gives non-square dsize): every transform t yields its OWN
+ * [3, ny_t, nx_t] image (gr_net_size of its crop), clamped to [0,1], not normalised.  Image i (= t, or c*T + t) is
+ * written at out + i * out_stride floats; out_stride >= the largest 3*ny*nx of the table (GR_EINVAL otherwise).
+ * The reference returns these as a Python list of differently sized tensors. */
+int gr_transform_composited_var(gr_ctx* ctx, const float* img, const float* mask_lg, const float* pert, int H, int W,
+                                const gr_xforms* xf, int net_size, float* out, int64_t out_stride, void* stream);
+int gr_warp_batch_var(gr_ctx* ctx, const float* img, int H, int W, const float* masks, const float* thetas, int C, int nh,
+                      int nw, const gr_xforms* xf, float lbd, int net_size, float* out, int64_t out_stride, void* stream);
 /* gr_transform_composited for callers that cannot allocate device memory (code under HIP graph capture, tight serving
  * loops, harnesses that forbid hipMalloc).  No counterpart in the reference.  Same arguments, same results bit for bit;
  * the composites (one RGBX f32 image per blur kernel in use, <= 4) are kept in a file-scope __device__ array of

@@ -264,8 +264,18 @@ static inline float gamma_stage(float v, const uint8_t* lut) {
     return r < 0.f ? 0.f : (r > 1.f ? 1.f : r);
 }
 
-int or_warp_one(const float* att, int H, int W, const or_xform* xf, int normalize, int net, float* out,
-                float* warped) {
+/* convert2Network's output size.  net_size == 32: 32 x 32 (transforms.py:19-23).  Otherwise (transforms.py:35-40) the
+ * short side becomes net_size and the long side int(round(net_size / short * long)): Python float arithmetic, round()
+ * = half to even = nearbyint in the default rounding mode. */
+void or_net_size(int crop_x, int crop_y, int net_size, int* nx, int* ny) {
+    if (net_size == 32) { *nx = *ny = 32; return; }
+    if (crop_y > crop_x) { *nx = net_size; *ny = (int)nearbyint((double)net_size / (double)crop_x * (double)crop_y); }
+    else { *ny = net_size; *nx = (int)nearbyint((double)net_size / (double)crop_y * (double)crop_x); }
+}
+
+/* warp + gamma + resize to ny x nx + clamp (+ -0.5) */
+static int warp_one_sized(const float* att, int H, int W, const or_xform* xf, int normalize, int nx, int ny, float* out,
+                          float* warped) {
     if (!att || !xf || !out || xf->crop_x <= 0 || xf->crop_y <= 0) return -1;
     int cw = xf->crop_x, chh = xf->crop_y;
     double Mi[9];
@@ -282,14 +292,27 @@ int or_warp_one(const float* att, int H, int W, const or_xform* xf, int normaliz
                 g[c * cpl + (size_t)y * cw + x] = gamma_stage(o3[c], xf->lut);
             }
         }
-    or_resize_linear(g, 3, chh, cw, out, net, net);        /* transforms.py:23 */
-    for (int i = 0; i < 3 * net * net; i++) {
+    or_resize_linear(g, 3, chh, cw, out, ny, nx);          /* transforms.py:23 / :42 */
+    for (int i = 0; i < 3 * nx * ny; i++) {
         float v = out[i];
-        v = v < 0.f ? 0.f : (v > 1.f ? 1.f : v);            /* :25 */
-        out[i] = normalize ? (v - 0.5f) : v;                /* :28 */
+        v = v < 0.f ? 0.f : (v > 1.f ? 1.f : v);            /* :25 / :44 */
+        out[i] = normalize ? (v - 0.5f) : v;                /* :28 (net_size 32, GTSRB only) */
     }
     free(g);
     return 0;
+}
+
+int or_warp_one(const float* att, int H, int W, const or_xform* xf, int normalize, int net, float* out,
+                float* warped) {
+    return warp_one_sized(att, H, W, xf, normalize, net, net, out, warped);
+}
+
+/* The net_size != 32 branch (transforms.py:31-45): out = [3, ny, nx] with (nx, ny) = or_net_size(crop), clamp only. */
+int or_warp_one_var(const float* att, int H, int W, const or_xform* xf, int net_size, float* out) {
+    int nx, ny;
+    if (!xf || net_size == 32) return -1;
+    or_net_size(xf->crop_x, xf->crop_y, net_size, &nx, &ny);
+    return warp_one_sized(att, H, W, xf, 0, nx, ny, out, NULL);
 }
 
 int or_warp_batch(const float* img, int H, int W, const float* masks, const float* thetas, int C, int nh, int nw,
@@ -316,6 +339,39 @@ int or_warp_batch(const float* img, int H, int W, const float* masks, const floa
 #pragma omp parallel for num_threads(nthreads) schedule(dynamic, 1)
         for (int t = 0; t < T; t++)
             or_warp_one(att[xf[t].blur], H, W, &xf[t], normalize, net, out + ((size_t)c * T + t) * on, NULL);
+        for (int b = 0; b < 8; b++) free(att[b]);
+        free(pert); free(ml);
+    }
+    return 0;
+}
+
+/* get_transformed_images with net_size != 32: image (c, t) at out + (c*T + t) * out_stride as [3, ny_t, nx_t] */
+int or_warp_batch_var(const float* img, int H, int W, const float* masks, const float* thetas, int C, int nh, int nw,
+                      const or_xform* xf, int T, float lbd, int net_size, float* out, long long out_stride, int nthreads) {
+    if (!img || !masks || !thetas || !xf || !out || C < 0 || T < 0 || net_size == 32) return -1;
+    size_t n = (size_t)3 * H * W, small = (size_t)3 * nh * nw;
+    int used[8] = {0};
+    for (int t = 0; t < T; t++) {
+        int b = xf[t].blur, nx, ny;
+        if (!(b == 0 || b == 3 || b == 5 || b == 7)) return -2;
+        used[b] = 1;
+        or_net_size(xf[t].crop_x, xf[t].crop_y, net_size, &nx, &ny);
+        if ((long long)3 * nx * ny > out_stride) return -3;
+    }
+    if (nthreads < 1) nthreads = 1;
+    for (int c = 0; c < C; c++) {
+        float* pert = (float*)malloc(sizeof(float) * n);
+        float* ml = (float*)malloc(sizeof(float) * n);
+        float* att[8] = {0};
+        or_add_noise(img, H, W, masks + c * small, thetas + c * small, nh, nw, lbd, 1, NULL, pert, ml);
+        for (int b = 0; b < 8; b++)
+            if (used[b]) {
+                att[b] = (float*)malloc(sizeof(float) * n);
+                or_composite(img, pert, ml, H, W, b, att[b]);
+            }
+#pragma omp parallel for num_threads(nthreads) schedule(dynamic, 1)
+        for (int t = 0; t < T; t++)
+            or_warp_one_var(att[xf[t].blur], H, W, &xf[t], net_size, out + ((size_t)c * T + t) * (size_t)out_stride);
         for (int b = 0; b < 8; b++) free(att[b]);
         free(pert); free(ml);
     }

@@ -55,6 +55,15 @@ int or_warp_one(const float* att, int H, int W, const or_xform* xf, int normaliz
 int or_warp_batch(const float* img, int H, int W, const float* masks, const float* thetas, int C, int nh, int nw,
                   const or_xform* xf, int T, float lbd, int normalize, int net, float* out, int nthreads);
 
+/* convert2Network's output size (transforms.py:19-23 for net_size 32, :35-40 otherwise). */
+void or_net_size(int crop_x, int crop_y, int net_size, int* nx, int* ny);
+/* The net_size != 32 branch (transforms.py:31-45) for frames of any aspect ratio (perspective_transform.py:39-44):
+ * out = [3, ny, nx] per transform, clamped, never normalised; or_warp_batch_var places image (c, t) at
+ * out + (c*T + t) * out_stride. */
+int or_warp_one_var(const float* att, int H, int W, const or_xform* xf, int net_size, float* out);
+int or_warp_batch_var(const float* img, int H, int W, const float* masks, const float* thetas, int C, int nh, int nw,
+                      const or_xform* xf, int T, float lbd, int net_size, float* out, long long out_stride, int nthreads);
+
 /* GTSRBNet (GTSRB/GTSRBNet.py:35-52).  tensors = 20 pointers in state_dict order
  * (conv1_1.weight, conv1_1.bias, ... fc7_1.weight, fc7_1.bias), PyTorch layouts. */
 int or_gtsrb_forward(const float* const* tensors, const float* x, int N, float* logits, int nthreads);

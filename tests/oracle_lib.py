@@ -93,6 +93,28 @@ def warp_batch(img, masks, thetas, xf, lbd=1.0, normalize=True, net=32, nthreads
     return out
 
 
+def net_size(crop_x, crop_y, net):
+    nx, ny = C.c_int(), C.c_int()
+    lib().or_net_size(int(crop_x), int(crop_y), int(net), C.byref(nx), C.byref(ny))
+    return nx.value, ny.value
+
+
+def warp_batch_var(img, masks, thetas, xf, net, lbd=1.0, nthreads=8):
+    """net_size != 32 branch: list (c-major) of [3, ny_t, nx_t] arrays."""
+    img, pi = _f(img); masks, pm = _f(masks); thetas, pt = _f(thetas)
+    _, H, W = img.shape
+    Cn, _, nh, nw = masks.shape
+    xf = np.ascontiguousarray(xf, dtype=XFORM_DTYPE)
+    T = xf.shape[0]
+    sizes = [net_size(int(t["crop_x"]), int(t["crop_y"]), net) for t in xf]
+    stride = max(3 * a * b for a, b in sizes)
+    out = np.zeros((Cn * T, stride), np.float32)
+    _check(lib().or_warp_batch_var(pi, H, W, pm, pt, Cn, nh, nw, xf.ctypes.data_as(C.c_void_p), T, C.c_float(lbd), int(net),
+                                   out.ctypes.data_as(C.c_void_p), C.c_longlong(stride), nthreads), "warp_batch_var")
+    return [out[i, :3 * sizes[i % T][0] * sizes[i % T][1]].reshape(3, sizes[i % T][1], sizes[i % T][0]).copy()
+            for i in range(Cn * T)]
+
+
 def _tensor_array(tensors):
     keep = [np.ascontiguousarray(t, dtype=np.float32) for t in tensors]
     arr = (C.c_void_p * len(keep))(*[t.ctypes.data for t in keep])
