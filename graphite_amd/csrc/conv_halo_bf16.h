@@ -142,7 +142,8 @@ void k_conv_halo_bf16(HaloBfParams p) {
         constexpr int PSTEP = NT / SEG;                   // pixels per pass
         constexpr int NPX = NIMG * THH * TWH;
         constexpr int IT = (NPX + PSTEP - 1) / PSTEP;
-        constexpr int UB = IT <= 26 ? IT : (IT + 1) / 2 <= 26 ? (IT + 1) / 2 : 16;   // loads in flight per thread
+        constexpr int UB0 = IT <= 26 ? IT : (IT + 1) / 2 <= 26 ? (IT + 1) / 2 : 16;   // loads in flight per thread
+        constexpr int UB = (IN_BF && UB0 > 4) ? 4 : UB0;   // bf16 input: a single fully unrolled batch (UB == IT) makes hipcc spill (228-308 B of scratch per lane, 3x the kernel time)
         static_assert(PSTEP / TWH + 1 <= THH, "tile too small for the incremental walk");
         const int seg = tid % SEG;
         int px = tid / SEG;

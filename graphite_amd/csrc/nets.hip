@@ -680,6 +680,9 @@ static int run_gtsrb_halo_bf16(gr_ctx* ctx, const Layer& L, int layer, const flo
             else HB(__VA_ARGS__, 3, false, true);                                                                  \
         } while (0)
         switch (layer) {
+        case 1: HB4( 32,  32, 16, 32, 1,  8, 1, 2, 1, 10, true ); break;
+        case 2: HB4( 32,  64, 16, 16, 1,  2, 2, 4, 1,  2, false); break;
+        case 3: HB4( 64,  64, 16, 16, 1,  4, 2, 2, 1,  4, true ); break;
         case 4: HB4( 64, 128,  8,  8, 2,  2, 4, 2, 1,  4, false); break;
         case 5: HB4(128, 128,  8,  8, 2,  2, 4, 2, 1,  4, true ); break;
         default: return gr_fail(ctx, GR_EINVAL, "conv_halo_bf16: layer %d", layer);
@@ -732,9 +735,11 @@ static int run_fc_bf16(gr_ctx* ctx, const Layer& L, const char* name, const floa
     return GR_OK;
 }
 
-// Measured per link (profiles/r01_bf16_tune.md): a bf16 INPUT costs the Cin <= 64 conv kernels registers and resident waves
-// (conv2_2 +0.9 ms, conv3_1 +0.9, conv3_2 +0.6, conv4_1 +0.3 per 32,000 images), so only the last three links are bf16.
-#define BF16_LINKS_DEFAULT 0x70
+// Every activation between two bf16 layers is stored as bf16 (links 0..6).  Round 1 kept the Cin <= 64 consumers on f32
+// inputs because their bf16-input instantiations were 1.5-3x slower; the cause was register spilling (228-308 bytes of
+// scratch per lane) when the tile-staging loop had all its loads in one unrolled batch -- fixed in conv_halo_bf16.h (UB),
+// after which every link is a gain (profiles/r02_bf16_links.txt: forward 8.10 -> 7.59 ms per 32,000 images).
+#define BF16_LINKS_DEFAULT 0x7f
 static bool small_launch_ok() {      // GRAPHITE_SMALL=0 turns the small-launch tilings off (A/B runs)
     static int v = -1;
     if (v < 0) { const char* e = getenv("GRAPHITE_SMALL"); v = (e && e[0] == '0') ? 0 : 1; }
@@ -765,7 +770,7 @@ static int gtsrb_forward(gr_ctx* ctx, gr_model* m, const float* x, int N, float*
         // links: bit i = the activation between layer i and layer i+1 (4: conv4_1 -> conv4_2, 5: conv4_2 -> fc5,
         // 6: fc5 -> fc6) is stored as bf16.  GRAPHITE_BF16_LINKS overrides the default (tuning).
         static int links_env = -1;
-        if (links_env < 0) { const char* e = getenv("GRAPHITE_BF16_LINKS"); links_env = e ? (int)strtol(e, nullptr, 0) & 0x70 : BF16_LINKS_DEFAULT; }
+        if (links_env < 0) { const char* e = getenv("GRAPHITE_BF16_LINKS"); links_env = e ? (int)strtol(e, nullptr, 0) & 0x7f : BF16_LINKS_DEFAULT; }
         const int links = (mask & 0xff) == 0x7f ? links_env : 0;
         auto lk = [&](int i) { return ((links >> i) & 1) != 0; };
         auto conv = [&](int l, const float* in, int H, float* out) {
