@@ -106,18 +106,46 @@ __global__ __launch_bounds__(256) void k_conv21_bf16(Conv21BfParams p) {
             }
         }
 
+    // epilogue through a wave-private LDS patch (conv_halo_bf16.h): 16-byte stores instead of one 2- / 4-byte store per value
+    __syncthreads();                                      // every wave is done with the tile and the weights: LDS is free
     const float bias = p.bias[lp];
+    {
+        constexpr int EROW = 144;
+        static_assert(4 * 32 * EROW <= WOFF + 10 * 1024, "epilogue patches must fit the kernel's LDS");
+        unsigned char* patch = sm + wave * (32 * EROW);
+        constexpr int CPV = OUT_BF ? 8 : 4, GPR = 32 / CPV, RPP = 64 / GPR, PASSES = 32 / RPP;
+        const int cg = lane % GPR, prow = lane / GPR;
 #pragma unroll
-    for (int i = 0; i < TM; i++) {
-        const int gy = y0 + wave * TM + i;
+        for (int i = 0; i < TM; i++) {
+            const int gy = y0 + wave * TM + i;
 #pragma unroll
-        for (int r = 0; r < 16; r++) {
-            const int gx = (r & 3) + 8 * (r >> 2) + 4 * lh;
-            float v = acc[i][r] + bias;
-            v = v > 0.f ? v : 0.f;
-            const size_t idx = (((size_t)b * H + gy) * W + gx) * 32 + lp;
-            if constexpr (OUT_BF) reinterpret_cast<__bf16*>(p.out)[idx] = (__bf16)v;
-            else reinterpret_cast<float*>(p.out)[idx] = v;
+            for (int r = 0; r < 16; r++) {
+                float v = acc[i][r] + bias;
+                v = v > 0.f ? v : 0.f;
+                *reinterpret_cast<float*>(patch + ((r & 3) + 8 * (r >> 2) + 4 * lh) * EROW + lp * 4) = v;
+            }
+            asm volatile("" ::: "memory");
+            f32x4v pv[PASSES][OUT_BF ? 2 : 1];
+#pragma unroll
+            for (int it = 0; it < PASSES; it++) {
+                const unsigned char* src = patch + (prow + RPP * it) * EROW + cg * (CPV * 4);
+                pv[it][0] = *reinterpret_cast<const f32x4v*>(src);
+                if constexpr (OUT_BF) pv[it][1] = *reinterpret_cast<const f32x4v*>(src + 16);
+            }
+            asm volatile("" ::: "memory");
+#pragma unroll
+            for (int it = 0; it < PASSES; it++) {
+                const int gx = prow + RPP * it;
+                const size_t off = (((size_t)b * H + gy) * W + gx) * 32 + cg * CPV;
+                if constexpr (OUT_BF) {
+                    bf16x8 h;
+#pragma unroll
+                    for (int e = 0; e < 4; e++) { h[e] = (__bf16)pv[it][0][e]; h[4 + e] = (__bf16)pv[it][1][e]; }
+                    *reinterpret_cast<bf16x8*>(reinterpret_cast<__bf16*>(p.out) + off) = h;
+                } else {
+                    *reinterpret_cast<f32x4v*>(reinterpret_cast<float*>(p.out) + off) = pv[it][0];
+                }
+            }
         }
     }
 }

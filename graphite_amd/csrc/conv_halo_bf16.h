@@ -251,48 +251,89 @@ void k_conv_halo_bf16(HaloBfParams p) {
         __syncthreads();
     });
 
-    // ---- epilogue (conv_halo.h) ----
-    auto store_out = [&](size_t idx, float v) {
-        if constexpr (OUT_BF) reinterpret_cast<__bf16*>(p.out)[idx] = (__bf16)v;
-        else reinterpret_cast<float*>(p.out)[idx] = v;
-    };
+    // ---- epilogue: + bias, ReLU, optional 2x2 max-pool, NHWC store ----
+    // An accumulator tile has its 32 output channels on the lanes and its pixels in the registers: stored directly that is
+    // one 2- or 4-byte access per value (16 per tile and lane), and a store costs the wave about as much as three MFMAs.
+    // Each tile therefore goes through a wave-private LDS patch (the loop's last barrier has retired every read of the
+    // input tile and of the weight buffers) and leaves as 16-byte stores: 8 bf16 (or 4 f32) channels of one pixel per lane.
+    {
+        constexpr int EROW = 144;                        // bytes per patch row: 32 channels x 4 B + 16 (9 slots, odd)
+        static_assert(NT / 64 * 32 * EROW <= G::LDS_BYTES, "epilogue patches must fit the kernel's LDS");
+        unsigned char* patch = smem_bf + wave * (32 * EROW);
+        constexpr int CPV = OUT_BF ? 8 : 4;              // channels per 16-byte store
+        constexpr int GPR = 32 / CPV;                    // lane groups per patch row
+        constexpr int RPP = 64 / GPR;                    // patch rows one pass of the wave covers
+        const int cg = lane % GPR, prow = lane / GPR;
+        constexpr int Hp_div = POOL ? 2 : 1;
+        const int Ho = p.H / Hp_div, Wo = p.W / Hp_div;
 #pragma unroll
-    for (int j = 0; j < TN; j++) {
-        const int co = (wn * TN + j) * 32 + lp;
-        const float bias = p.bias[co];
+        for (int j = 0; j < TN; j++) {
+            const int co = (wn * TN + j) * 32 + lp;
+            const float bias = p.bias[co];
+            const int cob = (wn * TN + j) * 32 + cg * CPV;
 #pragma unroll
-        for (int i = 0; i < TM; i++) {
-            const int mt = wm * TM + i;
-            if (POOL) {
-                constexpr int WPR = TW / 2, WPI = (TH / 2) * WPR;
-                const int Hp = p.H >> 1, Wp = p.W >> 1;
+            for (int i = 0; i < TM; i++) {
+                const int mt = wm * TM + i;
+                constexpr int ROWS = POOL ? 8 : 32;      // patch rows in use: pool windows or pixels of the tile
+                if (POOL) {
 #pragma unroll
-                for (int g = 0; g < 4; g++) {
-                    float v0 = acc[i][j][4 * g + 0] + bias, v1 = acc[i][j][4 * g + 1] + bias;
-                    float v2 = acc[i][j][4 * g + 2] + bias, v3 = acc[i][j][4 * g + 3] + bias;
-                    if (p.relu) {
-                        v0 = v0 > 0.f ? v0 : 0.f; v1 = v1 > 0.f ? v1 : 0.f;
-                        v2 = v2 > 0.f ? v2 : 0.f; v3 = v3 > 0.f ? v3 : 0.f;
+                    for (int g = 0; g < 4; g++) {
+                        float v0 = acc[i][j][4 * g + 0] + bias, v1 = acc[i][j][4 * g + 1] + bias;
+                        float v2 = acc[i][j][4 * g + 2] + bias, v3 = acc[i][j][4 * g + 3] + bias;
+                        if (p.relu) {
+                            v0 = v0 > 0.f ? v0 : 0.f; v1 = v1 > 0.f ? v1 : 0.f;
+                            v2 = v2 > 0.f ? v2 : 0.f; v3 = v3 > 0.f ? v3 : 0.f;
+                        }
+                        float mx = v0 > v1 ? v0 : v1;
+                        mx = mx > v2 ? mx : v2;
+                        mx = mx > v3 ? mx : v3;
+                        *reinterpret_cast<float*>(patch + (2 * g + lh) * EROW + lp * 4) = mx;
                     }
-                    float mx = v0 > v1 ? v0 : v1;
-                    mx = mx > v2 ? mx : v2;
-                    mx = mx > v3 ? mx : v3;
-                    int w = mt * 8 + 2 * g + lh;
-                    int im = w / WPI, r = w % WPI;
-                    int py = (y0 >> 1) + r / WPR, px = (x0 >> 1) + r % WPR;
-                    int gb = b0 + im;
-                    if (gb < p.B) store_out((((size_t)gb * Hp + py) * Wp + px) * COUT + co, mx);
-                }
-            } else {
+                } else {
 #pragma unroll
-                for (int r = 0; r < 16; r++) {
-                    int l = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                    int im = l / (TH * TW), q = l % (TH * TW);
-                    int gy = y0 + q / TW, gx = x0 + q % TW, gb = b0 + im;
-                    if (gb < p.B) {
+                    for (int r = 0; r < 16; r++) {
                         float v = acc[i][j][r] + bias;
                         if (p.relu) v = v > 0.f ? v : 0.f;
-                        store_out((((size_t)gb * p.H + gy) * p.W + gx) * COUT + co, v);
+                        *reinterpret_cast<float*>(patch + ((r & 3) + 8 * (r >> 2) + 4 * lh) * EROW + lp * 4) = v;
+                    }
+                }
+                // the patch is private to this wavefront and its LDS operations execute in order: only the compiler has to
+                // be kept from moving the reads above the writes (and the next tile's writes above these reads)
+                asm volatile("" ::: "memory");
+                constexpr int PASSES = (ROWS + RPP - 1) / RPP;
+                f32x4v pv[PASSES][OUT_BF ? 2 : 1];
+#pragma unroll
+                for (int it = 0; it < PASSES; it++) {
+                    const int row = prow + RPP * it;
+                    const unsigned char* src = patch + (row < ROWS ? row : 0) * EROW + cg * (CPV * 4);
+                    pv[it][0] = *reinterpret_cast<const f32x4v*>(src);
+                    if constexpr (OUT_BF) pv[it][1] = *reinterpret_cast<const f32x4v*>(src + 16);
+                }
+                asm volatile("" ::: "memory");
+#pragma unroll
+                for (int it = 0; it < PASSES; it++) {
+                    const int row = prow + RPP * it;
+                    if (row >= ROWS) continue;
+                    int gb, gy, gx;
+                    if (POOL) {
+                        constexpr int WPR = TW / 2, WPI = (TH / 2) * WPR;
+                        const int w = mt * 8 + row;
+                        const int im = w / WPI, r = w % WPI;
+                        gy = (y0 >> 1) + r / WPR; gx = (x0 >> 1) + r % WPR; gb = b0 + im;
+                    } else {
+                        const int l = mt * 32 + row;
+                        const int im = l / (TH * TW), q = l % (TH * TW);
+                        gy = y0 + q / TW; gx = x0 + q % TW; gb = b0 + im;
+                    }
+                    if (gb >= p.B) continue;
+                    const size_t off = (((size_t)gb * Ho + gy) * Wo + gx) * COUT + cob;
+                    if constexpr (OUT_BF) {
+                        bf16x8 h;
+#pragma unroll
+                        for (int e = 0; e < 4; e++) { h[e] = (__bf16)pv[it][0][e]; h[4 + e] = (__bf16)pv[it][1][e]; }
+                        *reinterpret_cast<bf16x8*>(reinterpret_cast<__bf16*>(p.out) + off) = h;
+                    } else {
+                        *reinterpret_cast<f32x4v*>(reinterpret_cast<float*>(p.out) + off) = pv[it][0];
                     }
                 }
             }
