@@ -227,16 +227,37 @@ extern "C" int gr_xforms_create(gr_ctx* ctx, const gr_xform* h, int T, gr_xforms
         d[t].pad_ = 0;
         memcpy(d[t].lut, h[t].lut, 256);
     }
+    // slot-major order and workgroup groups for the LDS-band warp kernel
+    std::vector<int> order;
+    std::vector<WarpGroup> groups;
+    x->all_sep = true;
+    for (int t = 0; t < T; t++) x->all_sep = x->all_sep && d[t].sep;
+    for (int s = 0; s < x->nslots; s++) {
+        const int first = (int)order.size();
+        for (int t = 0; t < T; t++)
+            if (d[t].slot == s) order.push_back(t);
+        for (int o = first; o < (int)order.size(); o += WARP_BAND_K) {
+            const int n = (int)order.size() - o < WARP_BAND_K ? (int)order.size() - o : WARP_BAND_K;
+            groups.push_back(WarpGroup{s, o, n, 0});
+        }
+    }
+    x->ngroups = (int)groups.size();
     hipError_t e = hipMalloc((void**)&x->dev, sizeof(XformDev) * T);
-    if (e != hipSuccess) { delete x; return gr_fail(ctx, GR_ENOMEM, "xforms hipMalloc: %s", hipGetErrorString(e)); }
+    if (e == hipSuccess) e = hipMalloc((void**)&x->order_dev, sizeof(int) * T);
+    if (e == hipSuccess) e = hipMalloc((void**)&x->groups_dev, sizeof(WarpGroup) * groups.size());
+    if (e != hipSuccess) { gr_xforms_destroy(x); return gr_fail(ctx, GR_ENOMEM, "xforms hipMalloc: %s", hipGetErrorString(e)); }
     e = hipMemcpy(x->dev, d.data(), sizeof(XformDev) * T, hipMemcpyHostToDevice);
-    if (e != hipSuccess) { (void)hipFree(x->dev); delete x; return gr_fail(ctx, GR_EHIP, "xforms upload: %s", hipGetErrorString(e)); }
+    if (e == hipSuccess) e = hipMemcpy(x->order_dev, order.data(), sizeof(int) * T, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(x->groups_dev, groups.data(), sizeof(WarpGroup) * groups.size(), hipMemcpyHostToDevice);
+    if (e != hipSuccess) { gr_xforms_destroy(x); return gr_fail(ctx, GR_EHIP, "xforms upload: %s", hipGetErrorString(e)); }
     *out = x;
     return GR_OK;
 }
 extern "C" void gr_xforms_destroy(gr_xforms* x) {
     if (!x) return;
     if (x->dev) (void)hipFree(x->dev);
+    if (x->order_dev) (void)hipFree(x->order_dev);
+    if (x->groups_dev) (void)hipFree(x->groups_dev);
     delete x;
 }
 

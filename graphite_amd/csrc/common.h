@@ -46,6 +46,10 @@ struct XformDev {
     uint8_t lut[256];
 };
 
+// one workgroup of k_warp_band: transforms order[first .. first + n) of one composite slot
+struct WarpGroup { int32_t slot, first, n, pad_; };
+constexpr int WARP_BAND_K = 16;
+
 struct gr_xforms {
     gr_ctx* ctx = nullptr;
     int T = 0;
@@ -53,6 +57,11 @@ struct gr_xforms {
     int nslots = 0;              // number of distinct blur kernels in the table
     int slot_blur[4] = {0, 0, 0, 0};   // blur kernel size of each slot
     std::vector<std::array<int, 2>> crop;   // host copy of (crop_x, crop_y) per transform
+    // k_warp_band: transforms sorted by composite slot and cut into groups of <= WARP_BAND_K (one workgroup each)
+    int* order_dev = nullptr;    // [T] transform indices, slot-major
+    WarpGroup* groups_dev = nullptr;
+    int ngroups = 0;
+    bool all_sep = false;        // every transform has Mi[1] == Mi[7] == 0
 };
 
 int gr_fail(gr_ctx* ctx, int code, const char* fmt, ...);

@@ -406,31 +406,44 @@ __global__ __launch_bounds__(256) void k_warp_net32(const float* __restrict__ at
     const size_t pl = (size_t)H * W;
     const float4* att = reinterpret_cast<const float4*>(att_all) + ((size_t)cand * nslots + x->slot) * pl;
     const double m4 = s_Mi[4], m5 = s_Mi[5];
-    const int nq = same ? 1 : 2;
 #pragma unroll 1
     for (int p = tid; p < net * net; p += 256) {
         const int oy = p >> 5, ox = p & 31;
         const Tap tx = s_tx[ox], ty = s_ty[oy];
         float g[2][2][3];
-        for (int jy = 0; jy < nq; jy++) {
-            const int y = jy ? ty.i1 : ty.i0;
-            for (int jx = 0; jx < nq; jx++) {
-                if (sep) {
-                    const WarpCol c = s_col[ox * 2 + jx];
-                    const double Y0 = (c.A + m4 * y) + m5;
+        if (sep) {
+            // straight-line 2 x 2 (a `same` image has coinciding taps with weights 1 and 0: the single sample, exactly), so
+            // that the coordinate chains and the 16 gathers of an output pixel are independent and overlap
+            const WarpCol cA = s_col[ox * 2], cB = s_col[ox * 2 + 1];
+            const double my[2] = {m4 * ty.i0, m4 * ty.i1};
+#pragma unroll
+            for (int jy = 0; jy < 2; jy++) {
+                float4 tp[2][4];
+                float w[2][4];
+#pragma unroll
+                for (int jx = 0; jx < 2; jx++) {
+                    const WarpCol& c = jx ? cB : cA;
+                    const double Y0 = (c.A + my[jy]) + m5;
                     const int Y = cv_round_sat((Y0 + c.B) * c.Wd);
                     const int sy = sat_short(Y >> 5);
                     const float fy = (float)(Y & 31) * (1.f / 32.f), fx = c.fx;
-                    const float w0 = (1.f - fy) * (1.f - fx), w1 = (1.f - fy) * fx, w2 = fy * (1.f - fx), w3 = fy * fx;
+                    w[jx][0] = (1.f - fy) * (1.f - fx); w[jx][1] = (1.f - fy) * fx; w[jx][2] = fy * (1.f - fx); w[jx][3] = fy * fx;
                     const int r0 = clipi(sy, 0, H) * W, r1 = clipi(sy + 1, 0, H) * W;
-                    const float4 a = att[r0 + c.sx0], b = att[r0 + c.sx1], cc = att[r1 + c.sx0], d = att[r1 + c.sx1];
-                    g[jy][jx][0] = gamma_stage_f(a.x * w0 + b.x * w1 + cc.x * w2 + d.x * w3, s_lutf);
-                    g[jy][jx][1] = gamma_stage_f(a.y * w0 + b.y * w1 + cc.y * w2 + d.y * w3, s_lutf);
-                    g[jy][jx][2] = gamma_stage_f(a.z * w0 + b.z * w1 + cc.z * w2 + d.z * w3, s_lutf);
-                } else {
-                    warp_gamma_rgbx(att, s_Mi, bw0, jx ? tx.i1 : tx.i0, y, H, W, s_lutf, g[jy][jx]);
+                    tp[jx][0] = att[r0 + c.sx0]; tp[jx][1] = att[r0 + c.sx1]; tp[jx][2] = att[r1 + c.sx0]; tp[jx][3] = att[r1 + c.sx1];
+                }
+#pragma unroll
+                for (int jx = 0; jx < 2; jx++) {
+                    g[jy][jx][0] = gamma_stage_f(tp[jx][0].x * w[jx][0] + tp[jx][1].x * w[jx][1] + tp[jx][2].x * w[jx][2] + tp[jx][3].x * w[jx][3], s_lutf);
+                    g[jy][jx][1] = gamma_stage_f(tp[jx][0].y * w[jx][0] + tp[jx][1].y * w[jx][1] + tp[jx][2].y * w[jx][2] + tp[jx][3].y * w[jx][3], s_lutf);
+                    g[jy][jx][2] = gamma_stage_f(tp[jx][0].z * w[jx][0] + tp[jx][1].z * w[jx][1] + tp[jx][2].z * w[jx][2] + tp[jx][3].z * w[jx][3], s_lutf);
                 }
             }
+        } else {
+#pragma unroll
+            for (int jy = 0; jy < 2; jy++)
+#pragma unroll
+                for (int jx = 0; jx < 2; jx++)
+                    warp_gamma_rgbx(att, s_Mi, bw0, jx ? tx.i1 : tx.i0, jy ? ty.i1 : ty.i0, H, W, s_lutf, g[jy][jx]);
         }
         float v[3];
         for (int c = 0; c < 3; c++) {
@@ -467,6 +480,274 @@ __global__ __launch_bounds__(256) void k_warp_net32(const float* __restrict__ at
             }
             reinterpret_cast<float4*>(out)[(size_t)local * (net * net) + p] = o4;
         }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// LDS-band warp: the north star's "LDS-staged source tiles".  OPT-IN (GRAPHITE_WARP_BAND=1): correct, bit-identical to
+// k_warp_net32, and slower than it on MI355X -- kept as the measured alternative (profiles/r02_warp_kernels.md).
+//
+// k_warp_net32 gathers its 16 taps per output pixel through L1: one image touches about half of the 128-byte lines of
+// its 952 KB composite and no line is reused, so a launch moves ~500 KB per image from L2 to L1 (profiles/README.md:
+// L2 -> L1 traffic is what bounds that kernel, not HBM and not the ALUs).  The source x of a destination column does
+// not depend on the row (WarpCol), so the taps of an output COLUMN live in a few adjacent source columns.  This
+// kernel turns the loop around: a workgroup takes WARP_BAND_K transforms that sample the SAME composite (candidate,
+// blur slot), walks the composite in vertical bands of BW source columns staged in LDS with coalesced 16-byte loads
+// (the next band is prefetched into registers while the current one is sampled), and in each band computes, for every one
+// of its images, the output columns whose taps fall inside the band.  A band is read once per K images: ~110 KB per
+// image instead of ~500 KB, and the gathers hit LDS.  Output columns whose footprint is wider than the band overlap
+// (HALO = BW - S columns; none in the reference's parameter ranges) are sampled from global memory instead.
+// Arithmetic: exactly k_warp_net32's separable path, value for value.
+// ---------------------------------------------------------------------------------------------
+constexpr int WB_NT = 1024;
+constexpr int WB_PRE = 8;                         // float4 prefetch registers per thread: H * BW <= WB_NT * WB_PRE
+
+struct BandCol {                                  // WarpCol, packed: A = Mi[3]*xb and B = Mi[3]*x1 are recomputed
+    double Wd;
+    short xb, x1, sx0, sx1;
+    float fx;
+    int pad_;
+};
+struct BandImg {                                  // per image of the workgroup
+    double m3, m4, m5;
+    int local, flags;                             // flags: 1 = same, 2 = area2; local < 0: image not in this launch
+    float txw0[32], txw1[32];                     // horizontal resize weights per output column
+    Tap ty[32];                                   // vertical resize taps per output row
+};
+constexpr size_t WB_TAIL = sizeof(BandCol) * WARP_BAND_K * 64 + sizeof(BandImg) * WARP_BAND_K + 1024 /* f255 */ +
+                           WARP_BAND_K * 256 /* lut8 */ + WARP_BAND_K * 32 /* band_of */ + 2 * WARP_BAND_K * 32 /* list */ +
+                           64 /* c11, counter */;
+
+template <int OUT>
+__global__ __launch_bounds__(WB_NT) void k_warp_band(const float* __restrict__ att_all, int H, int W, int nslots,
+                                                     const XformDev* __restrict__ xf, const int* __restrict__ order,
+                                                     const WarpGroup* __restrict__ groups, int G, int T, long long n_begin,
+                                                     int count, int cand_lo, int ncand, int cand0, int normalize, int BW, int S,
+                                                     int nb, const float* __restrict__ c11, float* __restrict__ out) {
+    constexpr int K = WARP_BAND_K, net = 32;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_wb[];
+    float4* band = reinterpret_cast<float4*>(smem_wb);                         // [H][BW], BW odd: rows land on distinct banks
+    unsigned char* tail = smem_wb + (size_t)H * BW * 16;
+    BandCol* cols = reinterpret_cast<BandCol*>(tail);                          // [K][64]
+    BandImg* imgs = reinterpret_cast<BandImg*>(tail + sizeof(BandCol) * K * 64);   // [K]
+    float* f255 = reinterpret_cast<float*>(reinterpret_cast<unsigned char*>(imgs) + sizeof(BandImg) * K);   // [256]
+    unsigned char* lut8 = reinterpret_cast<unsigned char*>(f255 + 256);        // [K][256]
+    unsigned char* band_of = lut8 + K * 256;                                   // [K][32]
+    unsigned short* list = reinterpret_cast<unsigned short*>(band_of + K * 32);   // [K*32] (image, column) pairs of a band
+    float* s_c11 = reinterpret_cast<float*>(list + K * 32);                    // [12]
+    int* s_cnt = reinterpret_cast<int*>(s_c11 + 12);
+
+    // workgroup -> (candidate, group); all groups of a candidate on one XCD (blockIdx % 8), whose L2 then holds its composites
+    const int xcd = blockIdx.x & 7, jb = blockIdx.x >> 3;
+    const int cl = (jb / G) * 8 + xcd;
+    if (cl >= ncand) return;
+    const WarpGroup g = groups[jb % G];
+    const int cand = cand_lo + cl;
+    const int tid = threadIdx.x;
+    const size_t pl = (size_t)H * W;
+    const float4* att = reinterpret_cast<const float4*>(att_all) + ((size_t)(cand - cand0) * nslots + g.slot) * pl;
+
+    // ---- per-image tables ----
+    {
+        const int k = tid >> 6, e = tid & 63;
+        const int t = k < g.n ? order[g.first + k] : -1;
+        const long long n = (long long)cand * T + (t >= 0 ? t : 0);
+        const bool live = t >= 0 && n >= n_begin && n < n_begin + count;
+        if (live) {
+            const XformDev* x = xf + t;
+            const int cw = x->crop_x, ch = x->crop_y, bw0 = x->bw0;
+            const bool same = (cw == net && ch == net);
+            const double scx = 1.0 / ((double)net / (double)cw), scy = 1.0 / ((double)net / (double)ch);
+            const int ox = e >> 1;
+            Tap tx;
+            if (same) { tx.i0 = tx.i1 = ox; tx.w0 = 1.f; tx.w1 = 0.f; } else tx = tap_h(ox, cw, scx);
+            const int xc = (e & 1) ? tx.i1 : tx.i0;
+            const double m0 = x->Mi[0], m2 = x->Mi[2], m6 = x->Mi[6], m8 = x->Mi[8];
+            const int xb = (xc / bw0) * bw0, x1 = xc - xb;
+            const double X0 = m0 * xb + m2;
+            const double W0 = m6 * xb + m8;
+            double Wd = W0 + m6 * x1;
+            Wd = 32.0 * (Wd != 0.0 ? 1.0 / Wd : 0.0);
+            const int X = cv_round_sat((X0 + m0 * x1) * Wd);
+            const int sx = sat_short(X >> 5);
+            BandCol c;
+            c.Wd = Wd; c.xb = (short)xb; c.x1 = (short)x1;
+            c.sx0 = (short)clipi(sx, 0, W); c.sx1 = (short)clipi(sx + 1, 0, W);
+            c.fx = (float)(X & 31) * (1.f / 32.f);
+            c.pad_ = 0;
+            cols[k * 64 + e] = c;
+            BandImg* im = imgs + k;
+            if (!(e & 1)) { im->txw0[ox] = tx.w0; im->txw1[ox] = tx.w1; }
+            if (e < 32) {
+                Tap ty;
+                if (same) { ty.i0 = ty.i1 = e; ty.w0 = 1.f; ty.w1 = 0.f; } else ty = tap_v(e, ch, scy);
+                im->ty[e] = ty;
+            }
+            if (e == 63) {
+                im->m3 = x->Mi[3]; im->m4 = x->Mi[4]; im->m5 = x->Mi[5];
+                im->local = (int)(n - n_begin);
+                im->flags = (same ? 1 : 0) | ((cw == 2 * net && ch == 2 * net) ? 2 : 0);
+            }
+            reinterpret_cast<unsigned int*>(lut8 + k * 256)[e] = reinterpret_cast<const unsigned int*>(x->lut)[e];
+        } else if (e == 63) {
+            imgs[k].local = -1;
+        }
+        if (tid < 256) f255[tid] = clamp01((float)((double)tid / 255.0));
+        if (OUT == GR_OUT_NHWC4_C11 && tid >= 256 && tid < 268) s_c11[tid - 256] = c11[tid - 256];
+    }
+    __syncthreads();
+    if (tid < K * 32) {                           // which band samples output column ox of image k
+        const int k = tid >> 5, ox = tid & 31;
+        unsigned char b = 254;                    // 254: no such image
+        if (imgs[k].local >= 0) {
+            const BandCol c0 = cols[k * 64 + 2 * ox], c1 = cols[k * 64 + 2 * ox + 1];
+            int lo = c0.sx0 < c1.sx0 ? c0.sx0 : c1.sx0, hi = c0.sx1 > c1.sx1 ? c0.sx1 : c1.sx1;
+            if (c0.sx1 > hi) hi = c0.sx1;
+            if (c1.sx0 < lo) lo = c1.sx0;
+            int bb = lo / S;
+            if (bb > nb - 1) bb = nb - 1;
+            b = (lo >= bb * S && hi < bb * S + BW) ? (unsigned char)bb : 255;     // 255: footprint wider than a band
+        }
+        band_of[tid] = b;
+    }
+
+    // ---- bands ----
+    const int npx = H * BW;                       // texels of a band (host guarantees npx <= WB_NT * WB_PRE)
+    float4 pre[WB_PRE];
+    auto fetch = [&](int b) {
+        const int c0 = b * S;
+#pragma unroll
+        for (int u = 0; u < WB_PRE; u++) {
+            const int i = tid + u * WB_NT;
+            const int row = i / BW, col = i - row * BW;
+            pre[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (i < npx && c0 + col < W) pre[u] = att[(size_t)row * W + c0 + col];
+        }
+    };
+    auto stash = [&]() {
+#pragma unroll
+        for (int u = 0; u < WB_PRE; u++) {
+            const int i = tid + u * WB_NT;
+            if (i < npx) band[i] = pre[u];
+        }
+    };
+    fetch(0);
+    stash();
+    if (tid == 0) *s_cnt = 0;
+    __syncthreads();
+    for (int b = 0; b < nb; b++) {
+        if (b + 1 < nb) fetch(b + 1);             // in flight while this band is sampled
+        // the (image, column) pairs of this band, compacted so that all 16 wavefronts share them evenly
+        if (tid < K * 32) {
+            const int bo = band_of[tid];
+            if (bo == b || (bo == 255 && b == 0)) {
+                const int idx = atomicAdd(s_cnt, 1);
+                list[idx] = (unsigned short)(tid | (bo == 255 ? 0x8000 : 0));
+            }
+        }
+        __syncthreads();
+        const int nitems = *s_cnt * 32;
+        const int c0 = b * S;
+#pragma unroll 1
+        for (int item = tid; item < nitems; item += WB_NT) {
+            const int ent = list[item >> 5], oy = item & 31;                  // a half-wave = the 32 rows of one column
+            const bool from_global = (ent & 0x8000) != 0;
+            const int k = (ent & 0x7fff) >> 5, ox = ent & 31;
+            const BandImg* im = imgs + k;
+            const int flags = im->flags;
+            const bool same = flags & 1, area2 = flags & 2;
+            const Tap ty = im->ty[oy];
+            const double m3 = im->m3, m4 = im->m4, m5 = im->m5;
+            const unsigned char* lut = lut8 + k * 256;
+            // All four warped pixels of the output pixel are evaluated in straight-line code (for a `same` image the two
+            // taps of an axis coincide and carry weights 1 and 0, which reproduces the single sample exactly): the
+            // coordinate chains, the 16 band reads and the 12 table look-ups are independent, so their latencies overlap.
+            const BandCol cA = cols[k * 64 + 2 * ox], cB = cols[k * 64 + 2 * ox + 1];
+            const double ax[2] = {m3 * (int)cA.xb, m3 * (int)cB.xb}, bx[2] = {m3 * (int)cA.x1, m3 * (int)cB.x1};
+            const double wd[2] = {cA.Wd, cB.Wd};
+            const float fxs[2] = {cA.fx, cB.fx};
+            const int sx0[2] = {cA.sx0, cB.sx0}, sx1[2] = {cA.sx1, cB.sx1};
+            const double my[2] = {m4 * ty.i0, m4 * ty.i1};
+            float gq[2][2][3];
+#pragma unroll
+            for (int jy = 0; jy < 2; jy++) {
+                int r0[2], r1[2];
+                float w[2][4];
+#pragma unroll
+                for (int jx = 0; jx < 2; jx++) {
+                    const double Y0 = (ax[jx] + my[jy]) + m5;
+                    const int Y = cv_round_sat((Y0 + bx[jx]) * wd[jx]);
+                    const int sy = sat_short(Y >> 5);
+                    const float fy = (float)(Y & 31) * (1.f / 32.f), fx = fxs[jx];
+                    w[jx][0] = (1.f - fy) * (1.f - fx); w[jx][1] = (1.f - fy) * fx; w[jx][2] = fy * (1.f - fx); w[jx][3] = fy * fx;
+                    r0[jx] = clipi(sy, 0, H); r1[jx] = clipi(sy + 1, 0, H);
+                }
+                float4 tp[2][4];
+#pragma unroll
+                for (int jx = 0; jx < 2; jx++) {
+                    if (!from_global) {
+                        const int q0 = sx0[jx] - c0, q1 = sx1[jx] - c0;
+                        tp[jx][0] = band[r0[jx] * BW + q0]; tp[jx][1] = band[r0[jx] * BW + q1];
+                        tp[jx][2] = band[r1[jx] * BW + q0]; tp[jx][3] = band[r1[jx] * BW + q1];
+                    } else {
+                        tp[jx][0] = att[(size_t)r0[jx] * W + sx0[jx]]; tp[jx][1] = att[(size_t)r0[jx] * W + sx1[jx]];
+                        tp[jx][2] = att[(size_t)r1[jx] * W + sx0[jx]]; tp[jx][3] = att[(size_t)r1[jx] * W + sx1[jx]];
+                    }
+                }
+#pragma unroll
+                for (int jx = 0; jx < 2; jx++) {
+                    const float v0 = tp[jx][0].x * w[jx][0] + tp[jx][1].x * w[jx][1] + tp[jx][2].x * w[jx][2] + tp[jx][3].x * w[jx][3];
+                    const float v1 = tp[jx][0].y * w[jx][0] + tp[jx][1].y * w[jx][1] + tp[jx][2].y * w[jx][2] + tp[jx][3].y * w[jx][3];
+                    const float v2 = tp[jx][0].z * w[jx][0] + tp[jx][1].z * w[jx][1] + tp[jx][2].z * w[jx][2] + tp[jx][3].z * w[jx][3];
+                    gq[jy][jx][0] = f255[lut[((int)(v0 * 255.0f)) & 255]];
+                    gq[jy][jx][1] = f255[lut[((int)(v1 * 255.0f)) & 255]];
+                    gq[jy][jx][2] = f255[lut[((int)(v2 * 255.0f)) & 255]];
+                }
+            }
+            const float txw0 = im->txw0[ox], txw1 = im->txw1[ox];
+            float v[3];
+#pragma unroll
+            for (int ch3 = 0; ch3 < 3; ch3++) {
+                float r;
+                if (same) r = gq[0][0][ch3];
+                else if (area2) r = ((((0.f + gq[0][0][ch3]) + gq[0][1][ch3]) + gq[1][0][ch3]) + gq[1][1][ch3]) * 0.25f;
+                else {
+                    const float h0 = gq[0][0][ch3] * txw0 + gq[0][1][ch3] * txw1;
+                    const float h1 = gq[1][0][ch3] * txw0 + gq[1][1][ch3] * txw1;
+                    r = h0 * ty.w0 + h1 * ty.w1;
+                }
+                r = clamp01(r);
+                v[ch3] = normalize ? r - 0.5f : r;
+            }
+            const int p = oy * 32 + ox;
+            const size_t local = (size_t)im->local;
+            if (OUT == GR_OUT_CHW) {
+                float* o = out + local * 3 * net * net;
+                for (int ch3 = 0; ch3 < 3; ch3++) o[ch3 * net * net + p] = v[ch3];
+            } else {
+                float4 o4;
+                if (OUT == GR_OUT_NHWC4_C11) {
+                    float r[3];
+#pragma unroll
+                    for (int q = 0; q < 3; q++) {
+                        float a1 = 0.f;
+                        a1 = fmaf(v[0], s_c11[q * 3 + 0], a1);
+                        a1 = fmaf(v[1], s_c11[q * 3 + 1], a1);
+                        a1 = fmaf(v[2], s_c11[q * 3 + 2], a1);
+                        a1 = a1 + s_c11[9 + q];
+                        r[q] = a1 > 0.f ? a1 : 0.f;
+                    }
+                    o4 = make_float4(r[0], r[1], r[2], 0.f);
+                } else {
+                    o4 = make_float4(v[0], v[1], v[2], 0.f);
+                }
+                reinterpret_cast<float4*>(out)[local * (net * net) + p] = o4;
+            }
+        }
+        __syncthreads();                          // every wave is done sampling this band (and reading its list)
+        if (tid == 0) *s_cnt = 0;
+        if (b + 1 < nb) stash();
+        __syncthreads();
     }
 }
 
@@ -560,6 +841,51 @@ int px_warp_net(gr_ctx* ctx, const float* att, int H, int W, const gr_xforms* xf
     if (out_mode == GR_OUT_NHWC4_C11 && !c11) return gr_fail(ctx, GR_EINVAL, "px_warp_net: conv1_1 parameters missing");
     // algorithmic bytes: 12 B/px written per image + 336 B of transform descriptor read
     ProfScope ps_(ctx, "k_warp_net", st, 0.0, (double)count * (12.0 * net * net + 336.0));
+    // LDS-band kernel (opt-in, GRAPHITE_WARP_BAND=1): bit-identical to the gather kernel but MEASURED SLOWER on MI355X
+    // (1.56-1.91 ms against 0.95 ms per 32,000 images, profiles/r02_warp_kernels.md): its inner loop is 600 instructions
+    // and ~50 LDS operations per output-pixel wavefront, which costs more than the gather kernel's 16 divergent loads.
+    static int band_on = -1;
+    if (band_on < 0) { const char* e = getenv("GRAPHITE_WARP_BAND"); band_on = (e && e[0] == '1') ? 1 : 0; }
+    if (band_on && net == 32 && var_stride == 0 && xf->all_sep && count >= 8 * WARP_BAND_K && H <= 2048) {
+        constexpr int HALO = 12;                 // widest footprint of an output column that a band must hold
+        const size_t tail = WB_TAIL;
+        int BW = (int)(((size_t)160 * 1024 - tail) / ((size_t)H * 16));
+        if (BW > WB_NT * WB_PRE / H) BW = WB_NT * WB_PRE / H;
+        if (!(BW & 1)) BW--;                     // odd row stride (in 16-byte slots): the rows of a column tap different banks
+        int S, nb;
+        if (BW >= W) { BW = W | 1; S = W; nb = 1; }
+        else { S = BW - HALO; nb = S > 0 ? (W + S - 1) / S : 0; }
+        if ((size_t)H * BW > (size_t)WB_NT * WB_PRE) S = 0;
+        if (S >= 8) {
+            const int cand_lo = (int)(n_begin / xf->T), cand_hi = (int)((n_begin + count - 1) / xf->T);
+            const int ncand = cand_hi - cand_lo + 1;
+            const size_t smem = (size_t)H * BW * 16 + tail;
+            const long long grid = (long long)((ncand + 7) / 8) * 8 * xf->ngroups;
+            if (grid <= 0x7fffffffLL) {
+#define WBK(M)                                                                                                              \
+                do {                                                                                                        \
+                    auto kern = k_warp_band<M>;                                                                             \
+                    static bool attr_set[64] = {false};                                                                     \
+                    int dev_ = 0;                                                                                           \
+                    GR_HIP(ctx, hipGetDevice(&dev_));                                                                       \
+                    if (dev_ >= 0 && dev_ < 64 && !attr_set[dev_]) {                                                        \
+                        GR_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                                \
+                                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));           \
+                        attr_set[dev_] = true;                                                                              \
+                    }                                                                                                       \
+                    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(WB_NT), smem, st, att, H, W, xf->nslots, xf->dev,   \
+                                       xf->order_dev, xf->groups_dev, xf->ngroups, xf->T, (long long)n_begin, count, cand_lo, \
+                                       ncand, cand0, normalize, BW, S, nb, c11, out);                                       \
+                } while (0)
+                if (out_mode == GR_OUT_CHW) WBK(GR_OUT_CHW);
+                else if (out_mode == GR_OUT_NHWC4) WBK(GR_OUT_NHWC4);
+                else WBK(GR_OUT_NHWC4_C11);
+#undef WBK
+                GR_HIP(ctx, hipGetLastError());
+                return GR_OK;
+            }
+        }
+    }
     static int xcd_map = -1;                     // GRAPHITE_WARP_XCD=0 turns the XCD-aware block order off (A/B runs)
     if (xcd_map < 0) { const char* e = getenv("GRAPHITE_WARP_XCD"); xcd_map = (e && e[0] == '0') ? 0 : 1; }
     const int use_map = (xcd_map && count >= 64) ? 1 : 0;
