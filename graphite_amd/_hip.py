@@ -372,7 +372,7 @@ class Model:
         return {0: "f32", 1: "bf16"}[v]
 
     def input_grad(self, x, target):
-        """(logits [N,ncls], d CE(logits_n, target) / d x_n [N,3,32,32]) as CUDA tensors; GTSRBNet only."""
+        """(logits [N,ncls], d CE(logits_n, target) / d x_n [N,3,32,32]) as CUDA tensors (GTSRBNet and WideResNet)."""
         xd = to_dev(x)
         if xd.dim() == 3:
             xd = xd[None]

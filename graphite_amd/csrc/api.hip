@@ -479,7 +479,11 @@ extern "C" int gr_model_input_grad(gr_ctx* ctx, gr_model* m, const float* x, int
     if (!m || !x || !grad_x || N < 0) return gr_fail(ctx, GR_EINVAL, "gr_model_input_grad: bad arguments");
     hipStream_t st = (hipStream_t)stream;
     const int ncls = gr_model_num_classes(m);
-    int chunk = N < 1024 ? N : 1024;                  // the pass keeps ~0.8 MB of activations per image
+    // the pass keeps every activation: ~0.8 MB per image for GTSRBNet, ~17 MB for WideResNet-34-10
+    int64_t cap = (int64_t)(ctx->ws_limit / (net_grad_workspace_bytes(m, 64) / 64 + 1));
+    if (cap < 1) cap = 1;
+    if (cap > 1024) cap = 1024;
+    int chunk = N < cap ? N : (int)cap;
     if (chunk <= 0) return GR_OK;
     int rc = gr_ws_reserve(ctx, net_grad_workspace_bytes(m, chunk), stream);
     if (rc) return rc;

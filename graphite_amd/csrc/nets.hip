@@ -32,6 +32,7 @@ struct WrnBlock {
     int cin, cout, stride;
     BnDev bn1, bn2;
     Layer conv1, conv2, sc;
+    Layer conv1T, conv2T, scT;   // transposed (input-gradient pass): flipped taps, Cin <-> Cout, stride 1 (strided layers run on the zero-dilated gradient)
     bool has_sc;
 };
 struct gr_model {
@@ -48,6 +49,7 @@ struct gr_model {
     Layer gb[9];             // the same layers transposed (input-gradient pass): conv with flipped taps / W^T
     // WideResNet
     Layer wconv1, wfc;
+    Layer wconv1T, wfcT;     // transposed, for gr_model_input_grad
     std::vector<WrnBlock> blocks;
     BnDev bnf;
     int ch[4] = {0, 0, 0, 0};
@@ -172,6 +174,17 @@ static int make_fc_bf16(gr_model* m, Layer* L, const float* w, int N, int K) {
     return GR_OK;
 }
 
+// Transposed conv for the input-gradient pass: dX = conv_stride1(dY (zero-dilated if the layer is strided), W') with
+// W'[ci][co][ky][kx] = W[co][ci][KH-1-ky][KW-1-kx], same padding.  w is OIHW.
+static int make_layer_T(gr_model* m, Layer* L, const float* w, int Co, int Ci, int KH, int KW, int pad) {
+    std::vector<float> wt((size_t)Co * Ci * KH * KW);
+    const int kk = KH * KW;
+    for (int o = 0; o < Co; o++)
+        for (int i = 0; i < Ci; i++)
+            for (int k = 0; k < kk; k++) wt[((size_t)i * Co + o) * kk + (kk - 1 - k)] = w[((size_t)o * Ci + i) * kk + k];
+    return make_layer(m, L, wt.data(), nullptr, Ci, Co, KH, KW, 1, pad);
+}
+
 // eval BatchNorm folded as PyTorch's CPU kernel does: alpha = w/sqrt(var+eps), beta = b - mean*alpha
 static int make_bn(gr_model* m, BnDev* bn, const float* w, const float* b, const float* mean, const float* var, int C) {
     int NP = (C + n_tile(C) - 1) / n_tile(C) * n_tile(C);
@@ -283,7 +296,9 @@ extern "C" int gr_model_load_wrn(gr_ctx* ctx, const float* const* t, const int64
     m->ctx = ctx; m->kind = 2; m->ncls = ncls;
     memcpy(m->ch, ch, sizeof(ch));
     int ti = 0, rc = expect(ctx, numel, 0, 16 * 3 * 9);
-    if (!rc) rc = make_layer(m, &m->wconv1, t[ti++], nullptr, 16, 3, 3, 3, 1, 1);
+    if (!rc) rc = make_layer(m, &m->wconv1, t[ti], nullptr, 16, 3, 3, 3, 1, 1);
+    if (!rc) rc = make_layer_T(m, &m->wconv1T, t[ti], 16, 3, 3, 3, 1);
+    ti++;
     for (int g = 0; g < 3 && !rc; g++)
         for (int i = 0; i < nb && !rc; i++) {
             WrnBlock b;
@@ -297,6 +312,7 @@ extern "C" int gr_model_load_wrn(gr_ctx* ctx, const float* const* t, const int64
             if (!rc) rc = expect(ctx, numel, ti, (int64_t)b.cout * b.cin * 9);
             if (!rc) rc = make_layer(m, &b.conv1, t[ti], nullptr, b.cout, b.cin, 3, 3, b.stride, 1);
             if (!rc && b.cin % 32 == 0 && b.cout % 160 == 0) rc = make_layer_bf16_cc(m, &b.conv1, t[ti], b.cout, b.cin);   // stride 1 and 2
+            if (!rc) rc = make_layer_T(m, &b.conv1T, t[ti], b.cout, b.cin, 3, 3, 1);
             ti++;
             for (int q = 0; q < 4 && !rc; q++) rc = expect(ctx, numel, ti + q, b.cout);
             if (!rc) rc = make_bn(m, &b.bn2, t[ti], t[ti + 1], t[ti + 2], t[ti + 3], b.cout);
@@ -304,10 +320,12 @@ extern "C" int gr_model_load_wrn(gr_ctx* ctx, const float* const* t, const int64
             if (!rc) rc = expect(ctx, numel, ti, (int64_t)b.cout * b.cout * 9);
             if (!rc) rc = make_layer(m, &b.conv2, t[ti], nullptr, b.cout, b.cout, 3, 3, 1, 1);
             if (!rc && b.cout % 160 == 0) rc = make_layer_bf16_cc(m, &b.conv2, t[ti], b.cout, b.cout);
+            if (!rc) rc = make_layer_T(m, &b.conv2T, t[ti], b.cout, b.cout, 3, 3, 1);
             ti++;
             if (b.has_sc) {
                 if (!rc) rc = expect(ctx, numel, ti, (int64_t)b.cout * b.cin);
                 if (!rc) rc = make_layer(m, &b.sc, t[ti], nullptr, b.cout, b.cin, 1, 1, b.stride, 0);
+                if (!rc) rc = make_layer_T(m, &b.scT, t[ti], b.cout, b.cin, 1, 1, 0);
                 ti++;
             }
             m->blocks.push_back(b);
@@ -318,6 +336,12 @@ extern "C" int gr_model_load_wrn(gr_ctx* ctx, const float* const* t, const int64
     if (!rc) rc = expect(ctx, numel, ti, (int64_t)ncls * ch[3]);
     if (!rc) rc = expect(ctx, numel, ti + 1, ncls);
     if (!rc) rc = make_layer(m, &m->wfc, t[ti], t[ti + 1], ncls, ch[3], 1, 1, 1, 0);
+    if (!rc) {      // fc^T with the logit gradients padded to 64 input channels (k_ce_grad's row width)
+        std::vector<float> wt((size_t)ch[3] * 64, 0.f);
+        for (int o = 0; o < ncls; o++)
+            for (int i = 0; i < ch[3]; i++) wt[(size_t)i * 64 + o] = t[ti][(size_t)o * ch[3] + i];
+        rc = make_layer(m, &m->wfcT, wt.data(), nullptr, ch[3], 64, 1, 1, 1, 0);
+    }
     if (rc) { gr_model_destroy(m); return rc; }
     *out = m;
     return GR_OK;
@@ -943,18 +967,22 @@ static size_t grad_floats_per_image() {
     //     x4     a21     a22     p2     a31     a32     p3     a41    a42    p4     f5     f6    lg   g64   gA      gB
     return 4096 + 32768 + 32768 + 8192 + 16384 + 16384 + 4096 + 8192 + 8192 + 2048 + 1024 + 1024 + 64 + 64 + 32768 + 32768;
 }
+static size_t wrn_grad_floats_per_image(const gr_model* m);
+static int wrn_input_grad(gr_ctx* ctx, gr_model* m, const float* x, int N, int target, float* logits_out, float* gx,
+                          float* w, hipStream_t st);
 size_t net_grad_workspace_bytes(const gr_model* m, int N) {
-    (void)m;
-    return gr_align(grad_floats_per_image() * sizeof(float) * (size_t)N);
+    const size_t per = m->kind == 2 ? wrn_grad_floats_per_image(m) : grad_floats_per_image();
+    return gr_align(per * sizeof(float) * (size_t)N);
 }
 
 // logits (optional) and d CE(logits_n, target) / d x_n for N images; GTSRBNet only.
 int net_input_grad(gr_ctx* ctx, gr_model* m, const float* x, int N, int target, float* logits_out, float* gx, char* wsb,
                    size_t ws_bytes, hipStream_t st) {
     if (N <= 0) return GR_OK;
-    if (m->kind != 1) return gr_fail(ctx, GR_EINVAL, "input gradients are implemented for GTSRBNet only");
     if (target < 0 || target >= m->ncls) return gr_fail(ctx, GR_EINVAL, "target %d out of range", target);
     if (ws_bytes < net_grad_workspace_bytes(m, N)) return gr_fail(ctx, GR_ESTATE, "net_input_grad: workspace too small");
+    if (m->kind == 2) return wrn_input_grad(ctx, m, x, N, target, logits_out, gx, (float*)wsb, st);
+    if (m->kind != 1) return gr_fail(ctx, GR_EINVAL, "unknown model kind");
     float* w = (float*)wsb;
     auto take = [&](size_t per) { float* p = w; w += per * (size_t)N; return p; };
     float *x4 = take(4096), *a21 = take(32768), *a22 = take(32768), *p2 = take(8192), *a31 = take(16384), *a32 = take(16384);
@@ -992,6 +1020,173 @@ int net_input_grad(gr_ctx* ctx, gr_model* m, const float* x, int N, int target, 
     if ((rc = run_conv(ctx, m->gb[1], gB, N, 32, 32, nullptr, nullptr, gA, nullptr, false, false, st, a21))) return rc;  // d a21
     if ((rc = run_conv(ctx, m->gb[0], gA, N, 32, 32, nullptr, nullptr, gB, nullptr, false, false, st))) return rc;       // d x4 [M,3]
     hipLaunchKernelGGL(k_input_grad, blocks((size_t)N * 1024), dim3(256), 0, st, gB, (const float4*)x4, m->c11, N, gx);
+    GR_HIP(ctx, hipGetLastError());
+    return GR_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// input gradient of WideResNet (whitebox_attack.py:155-158 with the CIFAR classifier, cifar/wideresnet.py:25-34,86-94)
+// ---------------------------------------------------------------------------------------------
+// backward of relu(bn(.)) in eval mode: g_pre = g_post * scale[c] where the activation is positive; optional + add[idx]
+__global__ void k_bn_relu_bwd(const float* __restrict__ g, const float* __restrict__ act, const float* __restrict__ scale,
+                              const float* __restrict__ add, size_t n, int C, float* __restrict__ out) {
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n) return;
+    const int c = (int)(idx % C);
+    float v = act[idx] > 0.f ? g[idx] * scale[c] : 0.f;
+    if (add) v = v + add[idx];
+    out[idx] = v;
+}
+// zero-dilation of a gradient for the transposed pass of a stride-2 layer: out[n, 2y, 2x, c] = g[n, y, x, c], 0 elsewhere
+__global__ void k_dilate2(const float* __restrict__ g, int N, int Ho, int Wo, int C, float* __restrict__ out) {
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int H = 2 * Ho, W = 2 * Wo;
+    if (idx >= (size_t)N * H * W * C) return;
+    const int c = (int)(idx % C);
+    size_t r = idx / C;
+    const int x = (int)(r % W); r /= W;
+    const int y = (int)(r % H);
+    const int n = (int)(r / H);
+    out[idx] = ((x | y) & 1) ? 0.f : g[(((size_t)n * Ho + (y >> 1)) * Wo + (x >> 1)) * C + c];
+}
+// backward of avg_pool2d(P pixels) after relu(bn(.)): g_y[n, p, c] = g_pooled[n, c] / P * scale[c] where act > 0
+__global__ void k_pool_bn_relu_bwd(const float* __restrict__ gp, const float* __restrict__ act, const float* __restrict__ scale,
+                                   int N, int P, int C, float* __restrict__ out) {
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (size_t)N * P * C) return;
+    const int c = (int)(idx % C);
+    const int n = (int)(idx / ((size_t)P * C));
+    out[idx] = act[idx] > 0.f ? (gp[(size_t)n * C + c] * (1.0f / (float)P)) * scale[c] : 0.f;
+}
+// [N, 1024, 3 of CP channels] NHWC -> [N, 3, 1024] CHW
+__global__ void k_nhwc_to_chw3(const float* __restrict__ g, int N, int CP, float* __restrict__ gx) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= N * 1024) return;
+    const int n = idx >> 10, p = idx & 1023;
+    for (int c = 0; c < 3; c++) gx[(size_t)n * 3072 + c * 1024 + p] = g[(size_t)idx * CP + c];
+}
+
+static size_t wrn_big(const gr_model* m) {
+    size_t big = (size_t)1024 * m->ch[1];
+    if ((size_t)256 * m->ch[2] > big) big = (size_t)256 * m->ch[2];
+    if ((size_t)64 * m->ch[3] > big) big = (size_t)64 * m->ch[3];
+    return big;
+}
+// gradient buffers also hold the zero-dilated gradient of a strided block: [Hi, Hi, cout] with Hi = 2 Ho
+static size_t wrn_gbig(const gr_model* m) {
+    size_t g = wrn_big(m);
+    int H = 32;
+    for (const WrnBlock& b : m->blocks) {
+        if (b.stride == 2 && (size_t)H * H * b.cout > g) g = (size_t)H * H * b.cout;
+        H /= b.stride;
+    }
+    return g;
+}
+static size_t wrn_grad_floats_per_image(const gr_model* m) {
+    size_t keep = 0;
+    int H = 32;
+    for (const WrnBlock& b : m->blocks) {
+        const int Ho = H / b.stride;
+        keep += (size_t)H * H * b.cin + (size_t)Ho * Ho * b.cout;      // o = relu(bn1(x)), u = relu(bn2(conv1(o)))
+        H = Ho;
+    }
+    keep += (size_t)H * H * m->ch[3];                                   // relu(bn(y_last))
+    //     x4    raw x ping-pong + shortcut   stored acts  pooled      logits g64   gradient buffers (4) + dilated
+    return 4096 + 3 * wrn_big(m) + keep + m->ch[3] + 64 + 64 + 5 * wrn_gbig(m);
+}
+
+static int wrn_input_grad(gr_ctx* ctx, gr_model* m, const float* x, int N, int target, float* logits_out, float* gx,
+                          float* w, hipStream_t st) {
+    const size_t big = wrn_big(m);
+    auto take = [&](size_t per) { float* p = w; w += per * (size_t)N; return p; };
+    auto blocks = [](size_t n) { return dim3((unsigned)((n + 255) / 256)); };
+    float* x4 = take(4096);
+    float *xr = take(big), *y = take(big), *s = take(big);
+    const size_t nb = m->blocks.size();
+    std::vector<float*> O(nb), U(nb);
+    {
+        int H = 32;
+        for (size_t bi = 0; bi < nb; bi++) {
+            const WrnBlock& b = m->blocks[bi];
+            const int Ho = H / b.stride;
+            O[bi] = take((size_t)H * H * b.cin);
+            U[bi] = take((size_t)Ho * Ho * b.cout);
+            H = Ho;
+        }
+    }
+    float* OF = take((size_t)64 * m->ch[3]);
+    float *pooled = take(m->ch[3]), *lg = take(64), *g64 = take(64);
+    const size_t gbig = wrn_gbig(m);
+    float *gY = take(gbig), *gA = take(gbig), *gB = take(gbig), *gS = take(gbig), *dil = take(gbig);
+    int rc;
+    // ---- forward, every post-activation kept (fp32 kernels, whatever gr_model_set_precision says) ----
+    hipLaunchKernelGGL(k_input_nhwc4<false>, blocks((size_t)N * 1024), dim3(256), 0, st, x, (const float*)nullptr, N, (float4*)x4);
+    if ((rc = run_conv(ctx, m->wconv1, x4, N, 32, 32, nullptr, &m->blocks[0].bn1, m->blocks[0].has_sc ? nullptr : xr, O[0],
+                       false, false, st))) return rc;
+    int H = 32;
+    for (size_t bi = 0; bi < nb; bi++) {
+        WrnBlock& b = m->blocks[bi];
+        const int Ho = H / b.stride;
+        if ((rc = run_conv(ctx, b.conv1, O[bi], N, H, H, nullptr, &b.bn2, nullptr, U[bi], false, false, st))) return rc;
+        const float* res = xr;
+        if (b.has_sc) {
+            if ((rc = run_conv(ctx, b.sc, O[bi], N, H, H, nullptr, nullptr, s, nullptr, false, false, st))) return rc;
+            res = s;
+        }
+        const bool last = bi + 1 == nb;
+        const BnDev* nbn = last ? &m->bnf : &m->blocks[bi + 1].bn1;
+        const bool need_raw = !last && !m->blocks[bi + 1].has_sc;
+        if ((rc = run_conv(ctx, b.conv2, U[bi], N, Ho, Ho, res, nbn, need_raw ? y : nullptr, last ? OF : O[bi + 1], false, false, st)))
+            return rc;
+        if (need_raw) { float* tmp = xr; xr = y; y = tmp; }
+        H = Ho;
+    }
+    const int C3 = m->ch[3], P = H * H;
+    hipLaunchKernelGGL(k_avgpool, blocks((size_t)N * C3), dim3(256), 0, st, OF, N, P, C3, pooled);
+    float* lgp = logits_out ? logits_out : lg;
+    if ((rc = run_conv(ctx, m->wfc, pooled, N, 1, 1, nullptr, nullptr, lgp, nullptr, false, false, st))) return rc;
+    // ---- backward ----
+    hipLaunchKernelGGL(k_ce_grad, blocks((size_t)N), dim3(256), 0, st, lgp, N, m->ncls, target, g64);
+    if ((rc = run_conv(ctx, m->wfcT, g64, N, 1, 1, nullptr, nullptr, gA, nullptr, false, false, st))) return rc;       // d pooled
+    hipLaunchKernelGGL(k_pool_bn_relu_bwd, blocks((size_t)N * P * C3), dim3(256), 0, st, gA, OF, m->bnf.scale, N, P, C3, gY);
+    for (size_t bi = nb; bi-- > 0;) {
+        WrnBlock& b = m->blocks[bi];
+        const int Ho = H, Hi = H * b.stride;             // block output / input size
+        const size_t mo = (size_t)N * Ho * Ho, mi = (size_t)N * Hi * Hi;
+        // d u = conv2^T(d y);  d conv1 = d u * bn2.scale where u > 0
+        if ((rc = run_conv(ctx, b.conv2T, gY, N, Ho, Ho, nullptr, nullptr, gA, nullptr, false, false, st))) return rc;
+        hipLaunchKernelGGL(k_bn_relu_bwd, blocks(mo * b.cout), dim3(256), 0, st, gA, U[bi], b.bn2.scale, (const float*)nullptr,
+                           mo * b.cout, b.cout, gB);
+        // d o = conv1^T(d conv1) [+ shortcut^T(d y)], strided layers on the zero-dilated gradients
+        const float* g1 = gB;
+        const float* gy_in = gY;
+        if (b.stride == 2) {
+            hipLaunchKernelGGL(k_dilate2, blocks(mi * b.cout), dim3(256), 0, st, gB, N, Ho, Ho, b.cout, dil);
+            g1 = dil;
+        }
+        const float* res = nullptr;
+        if (b.has_sc) {
+            if (b.stride == 2) {
+                hipLaunchKernelGGL(k_dilate2, blocks(mi * b.cout), dim3(256), 0, st, gY, N, Ho, Ho, b.cout, gA);
+                gy_in = gA;
+            }
+            if ((rc = run_conv(ctx, b.scT, gy_in, N, Hi, Hi, nullptr, nullptr, gS, nullptr, false, false, st))) return rc;
+            res = gS;
+        }
+        float* gO = (g1 == dil) ? gB : gA;               // a buffer neither operand lives in
+        if (b.has_sc && b.stride == 2) gO = gB;          // gA holds the dilated d y until scT has run (it has)
+        if ((rc = run_conv(ctx, b.conv1T, g1, N, Hi, Hi, res, nullptr, gO, nullptr, false, false, st))) return rc;
+        // d x = d o * bn1.scale where o > 0 (+ d y through the identity shortcut)
+        float* gX = (gO == gA) ? gB : gA;
+        hipLaunchKernelGGL(k_bn_relu_bwd, blocks(mi * b.cin), dim3(256), 0, st, gO, O[bi], b.bn1.scale,
+                           b.has_sc ? (const float*)nullptr : (const float*)gY, mi * b.cin, b.cin, gX);
+        float* old = gY; gY = gX;
+        if (gX == gA) gA = old; else gB = old;           // keep the three buffers distinct
+        H = Hi;
+    }
+    // d input = conv1^T(d x): [N,1024,3] (NP channels per pixel) -> CHW
+    if ((rc = run_conv(ctx, m->wconv1T, gY, N, 32, 32, nullptr, nullptr, gA, nullptr, false, false, st))) return rc;
+    hipLaunchKernelGGL(k_nhwc_to_chw3, blocks((size_t)N * 1024), dim3(256), 0, st, gA, N, 3, gx);
     GR_HIP(ctx, hipGetLastError());
     return GR_OK;
 }

@@ -7,8 +7,13 @@ transform_wb -> model -> CrossEntropy -> autograd.grad (:149-160) and then T mor
 here that is engine.eot_gradient (gr_wb_forward + gr_model_input_grad + gr_wb_backward) and one
 gr_wb_forward + gr_model_forward.  Query accounting (`num_queries`) follows :161 and :176.
 
-Not carried over: the pixel-wise removal branch (:228-243, unreachable with the script's hard-wired patch_removal=True),
-PNG outputs (the caller gets tensors), --gradient_shrink's cv2 round trip (:165-169) is done with the HIP resize.
+Both mask-shrinking branches are here: patch removal (:192-221, the script's hard-wired default) and the pixel-wise
+branch (:183-189, :222-236; `patch_removal=False`), which drops the `pixels_per_round` pixels with the smallest signed
+gradient sum per round and, when a round fails, restores the previous mask and halves that number.
+`model_type='CIFAR'` runs the same loop on a WideResNet (no -0.5 shift, :154-155; input gradients from
+gr_model_input_grad's WideResNet pass).
+Not carried over: PNG outputs (the caller gets tensors); --gradient_shrink's cv2 round trip (:165-169) is done with the
+HIP resize.
 """
 import numpy as np
 import torch
@@ -18,9 +23,11 @@ from .evaluator import TREvaluator
 from .transforms import build_wb_table, get_transform_params
 
 
-def wb_transform_robustness(model, img, adv, mask, tab, target):
+def wb_transform_robustness(model, img, adv, mask, tab, target, normalize=True):
     """eval() of the reference (:22-36): fraction of transforms whose arg-max is the target label."""
-    x = _hip.wb_forward(img, adv, mask, tab) - 0.5
+    x = _hip.wb_forward(img, adv, mask, tab)
+    if normalize:
+        x = x - 0.5
     preds = getattr(model, "hip_model", model).forward(x).argmax(dim=1)
     return float((preds == int(target)).sum().item()) / len(tab)
 
@@ -48,19 +55,48 @@ def _remove_patches(mask, score, size, interval, count):
     return removed
 
 
+def _remove_pixels(mask, grad, count):
+    """:222-236.  `count` times: g = mask * g; s = sum over channels (signed); s == 0 or NaN -> 999999; zero the mask at
+    the FIRST minimum of s.  A removed pixel turns into 999999 and nothing else changes, so the loop is a stable sort:
+    the `count` smallest live values go, in order; once only 999999 entries are left the first of them is hit again and
+    again (idempotent).  Returns the number of pixels whose mask changed."""
+    s = torch.sum(mask * grad, dim=0)
+    s = torch.where(s == 0, torch.full_like(s, 999999.0), s)
+    s = torch.nan_to_num(s, nan=999999.0, posinf=float("inf"), neginf=float("-inf"))
+    flat = s.flatten()
+    order = torch.sort(flat, stable=True).indices
+    live = int((flat < 999999.0).sum().item()) if bool((flat <= 999999.0).all()) else None
+    if live is None:                       # a genuine value above the sentinel: follow the loop literally
+        removed = 0
+        for _ in range(count):
+            i = int(torch.argmin(flat))
+            removed += int(mask.flatten(1)[0, i] > 0)
+            mask.flatten(1)[:, i] = 0
+            flat[i] = 999999.0 if not bool((mask.flatten(1)[:, i] != 0).any()) else flat[i]
+        return removed
+    take = order[:min(count, live)]
+    if count > live and live < flat.numel():
+        take = torch.cat([take, order[live:live + 1]])
+    before = int((mask.flatten(1)[0, take] > 0).sum().item())
+    mask.flatten(1)[:, take] = 0
+    return before
+
+
 def whitebox_attack(model, img, mask, target_label, pt_file, num_xforms=100, step_size=0.0156862745, iters=50, min_tr=0.8,
                     gradient_shrink=False, aligned=True, patch_removal_size=-1, patch_removal_interval=15.25,
-                    first_round_iters=500, max_rounds=None, xforms=None, verbose=False):
-    """img [3,H,W] in [0,1] (CPU or CUDA), mask [3,H,W] 0/1, model = graphite_amd.models.GTSRBNet.
-    Returns a dict: adversarial image and mask of the last round that reached `min_tr`, its transform robustness,
-    mask size (pixels), query count, rounds."""
+                    first_round_iters=500, max_rounds=None, xforms=None, verbose=False, patch_removal=True,
+                    pixels_per_round=5000, pixels_per_round_auto=True, model_type='GTSRB'):
+    """img [3,H,W] in [0,1] (CPU or CUDA), mask [3,H,W] 0/1, model = graphite_amd.models.GTSRBNet (or WideResNet with
+    model_type='CIFAR').  Returns a dict: adversarial image and mask of the last round that reached `min_tr`, its
+    transform robustness, mask size (pixels), query count, rounds."""
+    normalize = model_type == 'GTSRB'                                       # :154-155
     dev = _hip.to_dev(img).device
     img = _hip.to_dev(img)
     mask = _hip.to_dev(mask).clone()
     if patch_removal_size < 0:
         patch_removal_size = 30.5 if aligned else 30                        # :75-78
     if xforms is None:
-        xforms = get_transform_params(num_xforms, 'GTSRB')                   # :113
+        xforms = get_transform_params(num_xforms, model_type)                # :113
     tab = build_wb_table(xforms, img.shape[2], img.shape[1], pt_file)
     T = len(tab)
     num_queries = 0
@@ -77,7 +113,7 @@ def whitebox_attack(model, img, mask, target_label, pt_file, num_xforms=100, ste
         final_avg_grad, tr = None, 0.0
         loop_length = iters if rounds > 0 else first_round_iters           # :150
         for _ in range(loop_length):
-            avg_grad, _ = engine.eot_gradient(model, img, adv, mask, tab, target_label)
+            avg_grad, _ = engine.eot_gradient(model, img, adv, mask, tab, target_label, normalize=normalize)
             num_queries += T
             g = torch.nan_to_num(avg_grad, nan=0.0, posinf=float("inf"), neginf=float("-inf"))   # only NaN is zeroed (:164)
             if gradient_shrink:
@@ -86,20 +122,31 @@ def whitebox_attack(model, img, mask, target_label, pt_file, num_xforms=100, ste
             else:
                 g = torch.sign(g)
             adv = torch.clamp(adv - mask * step_size * g, 0, 1)              # :172-174
-            tr = wb_transform_robustness(model, img, adv, mask, tab, target_label)
+            tr = wb_transform_robustness(model, img, adv, mask, tab, target_label, normalize)
             num_queries += T
             final_avg_grad = avg_grad
             if verbose:
                 print("Iteration | Transform_Robustness: {:.2f}%".format(tr * 100))
             if tr >= min_tr:
                 break
-        # patch removal (:192-223): saliency = |mask * grad * perturbation| summed over channels
-        pert = adv - img
-        fg = torch.nan_to_num(final_avg_grad, nan=0.0, posinf=float("inf"), neginf=float("-inf"))
-        score = torch.sum(torch.abs(mask * fg * pert), dim=0).cpu().numpy()
-        mask_c = mask.cpu()
-        removed = _remove_patches(mask_c, score, patch_removal_size, patch_removal_interval, 4)
-        mask = mask_c.to(dev)
+        # :183-189: a failed pixel-wise round puts the previous mask back and halves the step (no new round is counted)
+        if not patch_removal and pixels_per_round_auto and tr < min_tr:
+            mask = previous_mask.clone()
+            pixels_per_round //= 2
+            history.append(dict(round=rounds, tr=tr, reset=True, pixels_per_round=pixels_per_round))
+            if pixels_per_round == 0:                                        # the reference would spin here for ever
+                break
+            continue
+        if patch_removal:
+            # :192-221: saliency = |mask * grad * perturbation| summed over channels, four patches per round
+            pert = adv - img
+            fg = torch.nan_to_num(final_avg_grad, nan=0.0, posinf=float("inf"), neginf=float("-inf"))
+            score = torch.sum(torch.abs(mask * fg * pert), dim=0).cpu().numpy()
+            mask_c = mask.cpu()
+            removed = _remove_patches(mask_c, score, patch_removal_size, patch_removal_interval, 4)
+            mask = mask_c.to(dev)
+        else:
+            removed = _remove_pixels(mask, final_avg_grad, pixels_per_round)   # :222-236
         history.append(dict(round=rounds, tr=tr, removed=removed))
         if tr < min_tr:                                                      # :246-253: keep the previous round's result
             break

@@ -172,10 +172,13 @@ int gr_model_forward(gr_ctx* ctx, gr_model* m, const float* x, int N, float* log
 int gr_model_predict(gr_ctx* ctx, gr_model* m, const float* x, int N, int64_t* preds, void* stream);
 
 /* Input gradient of the classifier for the whitebox EOT loop (whitebox_attack.py:155-158:
- * logits = model(x); loss = CrossEntropyLoss(logits, target); grad = autograd.grad(loss, x)), GTSRBNet only:
- * grad_x [N,3,32,32] dev = d CE(logits_n, target) / d x_n PER IMAGE (no averaging over N); logits [N,43] dev optional.
- * Forward with every activation kept (GTSRBNet.py:35-52), then the transposed layers on the same MFMA kernels
+ * logits = model(x); loss = CrossEntropyLoss(logits, target); grad = autograd.grad(loss, x)):
+ * grad_x [N,3,32,32] dev = d CE(logits_n, target) / d x_n PER IMAGE (no averaging over N); logits [N,ncls] dev optional.
+ * GTSRBNet: forward with every activation kept (GTSRBNet.py:35-52), then the transposed layers on the same MFMA kernels
  * (flipped 5x5 taps, W^T), ReLU / max-pool routing as torch's autograd does (first maximum of a window).
+ * WideResNet (cifar/wideresnet.py:25-34, 86-94): every post-activation kept, then per block in reverse the transposed 3x3
+ * convs (strided layers on the zero-dilated gradient), eval-BatchNorm scale and ReLU gates, 1x1 / identity shortcuts,
+ * average-pool and linear backward.  ~17 MB of workspace per image for WRN-34-10 (chunked under the workspace limit).
  * Always fp32, whatever gr_model_set_precision says. */
 int gr_model_input_grad(gr_ctx* ctx, gr_model* m, const float* x, int N, int target, float* logits, float* grad_x,
                         void* stream);

@@ -35,3 +35,13 @@ def forward(sd, x, depth=34, widen=10, bf16=False):
     out = F.relu(_bn(sd, "bn1", out))
     out = F.avg_pool2d(out, 8).reshape(-1, ch[3])
     return F.linear(out, sd["fc.weight"], sd["fc.bias"])
+
+
+def input_grad(sd, x, target, depth=34, widen=10):
+    """(logits, d CE(logits_n, target) / d x_n) per image (reduction='sum'): torch autograd of forward() is the
+    reference of gr_model_input_grad for WideResNet (the classifier half of whitebox_attack.py:155-158)."""
+    x = x.clone().requires_grad_(True)
+    logits = forward(sd, x, depth, widen)
+    loss = F.cross_entropy(logits, torch.full((x.shape[0],), int(target), dtype=torch.long), reduction="sum")
+    g, = torch.autograd.grad(loss, x)
+    return logits.detach(), g

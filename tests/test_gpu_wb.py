@@ -195,3 +195,131 @@ def test_whitebox_attack_loop_runs_and_shrinks_the_mask():
     assert float(adv.min()) >= 0 and float(adv.max()) <= 1
     outside = (mask < 0.5)
     assert torch.equal(adv.cpu()[outside], img[outside])                      # nothing changes outside the starting mask
+
+
+@pytest.mark.parametrize("depth,widen,ncls,n", [(10, 2, 10, 9), (16, 1, 7, 6), (34, 10, 10, 3)])
+def test_wideresnet_input_gradient_matches_torch_autograd(depth, widen, ncls, n):
+    """d CE / d x through WideResNet (pre-activation blocks: eval BatchNorm, ReLU, 3x3 convs of stride 1 and 2, 1x1 and
+    identity shortcuts, average pool, linear) against torch autograd of oracle/wrn_torch_reference.py.
+    depth 10 / widen 2: every block has a 1x1 shortcut; depth 16 / widen 1: identity shortcuts too; 34-10: the halo kernels.
+    Same bars as GTSRBNet's: ReLU sign flips at pre-activations within rounding of zero are legitimate differences."""
+    import wrn_torch_reference as W
+    from graphite_amd import models, synth
+    sd = synth.wrn_state_dict("wrn-grad-%d-%d" % (depth, widen), depth=depth, widen=widen, num_classes=ncls,
+                              calibrated=False)
+    m = models.WideResNet(depth=depth, num_classes=ncls, widen_factor=widen)
+    m.load_state_dict(sd)
+    sdt = {k: torch.from_numpy(np.asarray(v)) for k, v in sd.items() if not k.startswith("sub_block1")}
+    x = torch.from_numpy(synth.synth_images("wrn-grad", n, 0.0, 1.0))
+    target = 3
+    lg_ref, g_ref = W.input_grad(sdt, x, target, depth, widen)
+    lg, g = m.hip_model.input_grad(x, target)
+    lg, g = lg.cpu(), g.cpu()
+    assert float((lg - lg_ref).abs().max()) <= 1e-4 * float(lg_ref.abs().max())
+    assert torch.equal(lg, m.forward(x).cpu())                              # the inference path's logits, bit for bit
+    scale = g_ref.abs().amax(dim=(1, 2, 3))
+    err = (g - g_ref).abs().amax(dim=(1, 2, 3))
+    assert float(scale.min()) > 0
+    rel_l2 = (g - g_ref).flatten(1).norm(dim=1) / g_ref.flatten(1).norm(dim=1)
+    print("wrn-%d-%d max err / scale" % (depth, widen), (err / scale).tolist(), "rel l2", rel_l2.tolist())
+    if depth < 34:
+        assert float((err <= 2e-5 * scale).float().mean()) >= 0.6, (err / scale).tolist()
+        assert float(rel_l2.max()) <= 0.25, rel_l2.tolist()
+    else:
+        # 33 conv layers and ~3 M activations per image: a handful of ReLU decisions at pre-activations within rounding
+        # of zero differ between torch's summation order and the k-ordered MFMA chain in most images (measured: max
+        # element error 3e-6 .. 8e-3 of the largest gradient, relative L2 <= 1e-2)
+        assert float((err / scale).max()) <= 5e-2 and float(rel_l2.max()) <= 5e-2, (err / scale).tolist()
+
+
+def test_eot_gradient_cifar_wideresnet():
+    """engine.eot_gradient with model_type CIFAR: transform_wb (no -0.5) -> WideResNet -> CE -> d/d adv, all on the GPU,
+    against torch autograd of the two restatements chained."""
+    import wrn_torch_reference as W
+    from cases import cifar_case
+    from graphite_amd import engine, models, synth
+    c = cifar_case(num_xforms=6)
+    sd = synth.wrn_state_dict("wrn-small", depth=10, widen=2, num_classes=10)
+    m = models.WideResNet(depth=10, num_classes=10, widen_factor=2)
+    m.load_state_dict(sd)
+    sdt = {k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}
+    g0 = torch.Generator().manual_seed(5)
+    orig = torch.from_numpy(0.05 + 0.9 * c["vic"])
+    adv = torch.clamp(orig + 0.2 * torch.randn(orig.shape, generator=g0), 0.03, 0.97)
+    mask = torch.ones(3, 32, 32)
+    tab = T.build_wb_table(c["xf"], 32, 32, None)
+    grad, logits = engine.eot_gradient(m, orig, adv, mask, tab, 4, pt_file=None, normalize=False)
+    a = adv.clone().requires_grad_(True)
+    outs = [R.transform_wb(orig[None], a[None], mask, c["tab"][t]["M"].reshape(3, 3), int(c["tab"][t]["crop_x"]),
+                           int(c["tab"][t]["crop_y"]), float(c["xf"][t][2]), int(c["xf"][t][3])) for t in range(6)]
+    lg_ref = W.forward(sdt, torch.cat(outs), 10, 2)
+    loss = torch.nn.functional.cross_entropy(lg_ref, torch.full((6,), 4, dtype=torch.long), reduction="sum") / 6
+    g_ref, = torch.autograd.grad(loss, a)
+    assert float((logits.cpu() - lg_ref.detach()).abs().max()) <= 1e-4 * float(lg_ref.abs().max())
+    err = float((grad.cpu() - g_ref).abs().max()) / float(g_ref.abs().max())
+    assert err <= 1e-3, err
+
+
+def test_whitebox_pixelwise_branch_and_its_reference_loop():
+    """The pixel-wise removal branch (reference whitebox_attack.py:183-189, :222-236).  _remove_pixels is a closed form of
+    the reference's per-pixel loop: checked here against that loop written out literally, then the driver is run with
+    patch_removal=False (rounds succeed, the mask loses pixels_per_round pixels per round, a failed round halves the step)."""
+    import random
+    from cases import INP
+    from graphite_amd.imageio import load_image_chw, load_image_u8_hwc, resize_u8_linear
+    from graphite_amd.whitebox_attack import whitebox_attack, _remove_pixels
+    g = torch.Generator().manual_seed(3)
+    for case in range(3):
+        mask = (torch.rand(1, 12, 15, generator=g) > 0.4).float().repeat(3, 1, 1)
+        grad = torch.randn(3, 12, 15, generator=g)
+        grad[:, 2, 3] = 0.0                                                   # a live pixel with a zero sum
+        grad[0, 5, 5] = float("nan")
+        count = (7, 60, 400)[case]                                            # fewer than / about / more than the live pixels
+        ref_mask, fg = mask.clone(), grad.clone()
+        for _ in range(count):                                               # :223-235, literally
+            fg = ref_mask * fg
+            s = torch.sum(fg, dim=0)
+            s = torch.where(s == 0, torch.tensor(999999).float(), s)
+            s[torch.isnan(s)] = 999999
+            idx = (s == torch.min(s)).nonzero()[0]
+            ref_mask[(0,) + tuple(idx)] = 0
+            ref_mask[(1,) + tuple(idx)] = 0
+            ref_mask[(2,) + tuple(idx)] = 0
+        got = mask.clone()
+        _remove_pixels(got, grad, count)
+        assert torch.equal(got, ref_mask), case
+    m, _ = _toy_model()
+    img = torch.from_numpy(load_image_chw(os.path.join(INP, "GTSRB/images/14.png")))
+    hull = resize_u8_linear(load_image_u8_hwc(os.path.join(INP, "GTSRB/Hulls/14.png")), 244, 244)
+    mask = torch.from_numpy((np.where(hull > 128, 255, 0).transpose(2, 0, 1) / 255.0).astype(np.float32))
+    np.random.seed(42); torch.manual_seed(42); random.seed(42)
+    xforms = T.get_transform_params(20, 'GTSRB')
+    r = whitebox_attack(m, img, mask, 27, PT14, step_size=4 / 255, iters=20, min_tr=0.6, first_round_iters=60, max_rounds=2,
+                        xforms=xforms, patch_removal=False, pixels_per_round=3000)
+    assert r["rounds"] >= 1 and r["transform_robustness"] >= 0.6
+    start = int(mask[0].sum())
+    ok_rounds = [h for h in r["history"] if not h.get("reset")]
+    assert ok_rounds and ok_rounds[0]["removed"] == 3000 and r["mask_size"] <= start - 3000
+    assert float((r["mask"].cpu() - mask).max()) <= 0
+
+
+def test_whitebox_attack_cifar_wideresnet_runs():
+    """The same driver with model_type='CIFAR': WideResNet gradients (gr_model_input_grad), no -0.5 shift."""
+    import random
+    from cases import cifar_case
+    from graphite_amd import models, synth
+    from graphite_amd.whitebox_attack import whitebox_attack
+    c = cifar_case(num_xforms=10)
+    sd = synth.wrn_state_dict("wrn-small", depth=10, widen=2, num_classes=10)
+    m = models.WideResNet(depth=10, num_classes=10, widen_factor=2)
+    m.load_state_dict(sd)
+    img = torch.from_numpy(0.05 + 0.9 * c["vic"])
+    mask = torch.ones(3, 32, 32)
+    clean = int(m.predict(img).item()) if hasattr(m.predict(img), "item") else int(m.predict(img))
+    target = (clean + 1) % 10
+    np.random.seed(42); torch.manual_seed(42); random.seed(42)
+    r = whitebox_attack(m, img, mask, target, None, step_size=4 / 255, iters=10, min_tr=0.5, first_round_iters=80, max_rounds=1,
+                        xforms=c["xf"], patch_removal_size=8, patch_removal_interval=4, model_type='CIFAR')
+    assert r["queries"] > 0 and r["queries"] % 20 == 0
+    if r["rounds"] >= 1:                                                      # the attack reached min_tr on the untrained net
+        assert r["transform_robustness"] >= 0.5 and r["mask_size"] < 1024
