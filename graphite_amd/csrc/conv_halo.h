@@ -247,6 +247,7 @@ __global__ __launch_bounds__(WM* WN * 64) void k_conv_halo(HaloParams p) {
     }
 
     // ---- epilogue ----
+    if (!POOL) __syncthreads();                   // the LDS patches below overlay the input tile other waves may still read
     // Row r of an accumulator tile belongs to tile row i_r = (r&3) + 8*(r>>2) + 4*lh, i.e. NOT this lane's
     // own `lp` pixel: recompute the pixel of each row from the m-tile mapping.
 #pragma unroll
@@ -278,16 +279,32 @@ __global__ __launch_bounds__(WM* WN * 64) void k_conv_halo(HaloParams p) {
                     if (cok && gb < p.B) p.out[(((size_t)gb * Hp + py) * Wp + px) * p.Cout + co] = mx;
                 }
             } else {
+                // 32 pixels x 32 channels of f32: through a wave-private LDS patch so that the tile leaves as 16-byte stores
+                // (4 consecutive channels of one pixel per lane) instead of 16 scalar stores per lane -- for conv2_1, whose
+                // tiles are only 50 MFMAs deep, the scalar stores were half the kernel's time.  Values are unchanged.
+                constexpr int EROW = 144;                // bytes per patch row: 32 x 4 + 16 (an odd number of 16-byte slots)
+                unsigned char* patch = reinterpret_cast<unsigned char*>(smem) + wave * (32 * EROW);
 #pragma unroll
                 for (int r = 0; r < 16; r++) {
-                    int l = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                    int im = l / (TH * TW), q = l % (TH * TW);
-                    int gy = y0 + q / TW, gx = x0 + q % TW, gb = b0 + im;
-                    if (cok && gb < p.B) {
-                        float v = acc[i][j][r] + bias;
-                        if (p.relu) v = v > 0.f ? v : 0.f;
-                        p.out[(((size_t)gb * p.H + gy) * p.W + gx) * p.Cout + co] = v;
-                    }
+                    float v = acc[i][j][r] + bias;
+                    if (p.relu) v = v > 0.f ? v : 0.f;
+                    *reinterpret_cast<float*>(patch + ((r & 3) + 8 * (r >> 2) + 4 * lh) * EROW + lp * 4) = v;
+                }
+                asm volatile("" ::: "memory");           // wave-private patch, in-order LDS: only the compiler must not reorder
+                typedef float f32x4h __attribute__((ext_vector_type(4)));
+                const int c4 = lane & 7, prow = lane >> 3;
+                f32x4h pv[4];
+#pragma unroll
+                for (int it = 0; it < 4; it++) pv[it] = *reinterpret_cast<const f32x4h*>(patch + (prow + 8 * it) * EROW + c4 * 16);
+                asm volatile("" ::: "memory");
+                const int cob = (wn * TN + j) * 32 + c4 * 4;
+#pragma unroll
+                for (int it = 0; it < 4; it++) {
+                    const int l = mt * 32 + prow + 8 * it;
+                    const int im = l / (TH * TW), q = l % (TH * TW);
+                    const int gy = y0 + q / TW, gx = x0 + q % TW, gb = b0 + im;
+                    if (gb < p.B && cob < p.Cout)
+                        *reinterpret_cast<f32x4h*>(p.out + (((size_t)gb * p.H + gy) * p.W + gx) * p.Cout + cob) = pv[it];
                 }
             }
         }
@@ -298,7 +315,9 @@ __global__ __launch_bounds__(WM* WN * 64) void k_conv_halo(HaloParams p) {
 template <int CIN, int CPH, int KH, int KW, int PS, int TH, int TW, int NIMG, int WM, int WN, int TM, int TN, int KU, int NP,
           bool POOL, int PIPE = 0>
 static inline hipError_t launch_conv_halo(const HaloParams& p, hipStream_t st) {
-    constexpr size_t smem = sizeof(float) * ((size_t)NIMG * (TH + 4) * ((TW + 4) * PS + 32) + 32);
+    constexpr size_t tile_b = sizeof(float) * ((size_t)NIMG * (TH + 4) * ((TW + 4) * PS + 32) + 32);
+    constexpr size_t patch_b = POOL ? 0 : (size_t)WM * WN * 32 * 144;     // epilogue patches overlay the tile
+    constexpr size_t smem = tile_b > patch_b ? tile_b : patch_b;
     auto kern = k_conv_halo<CIN, CPH, KH, KW, PS, TH, TW, NIMG, WM, WN, TM, TN, KU, NP, POOL, PIPE>;
     // the attribute is per device: one flag per device this process launches on
     static bool attr_set[64] = {false};
