@@ -211,6 +211,7 @@ def extras(_hip, engine, models, synth):
     res["config2_gtsrb_attack"] = {
         "wall_clock_s": dt, "queries": int(r["queries"]), "mask_queries": int(r["mask_queries"]),
         "boost_queries": int(r["boost_queries"]), "queries_per_s": r["queries"] / dt,
+        "queries_issued_including_discarded_speculation": int(r.get("queries_issued", r["queries"])),
         "final_mask_pixels": int(r["pixels"]), "transform_robustness": float(r["transform_robustness"]),
         "note": "stop sign 14 -> pedestrians 27, -m 100 -b 100, binary coarse reduction, seed 42; seeded GTSRBNet with a fitted "
                 "3-sign read-out (the authors' checkpoint is unavailable; reference: ~10 min on an RTX 3080, README.md:26)"}
@@ -390,6 +391,9 @@ def main():
                    "sharding": "contiguous slices of the (candidate x transform) index, one int32[C] all-reduce",
                    "backend": (backend if world > 1 else None),
                    "rehearsal_all_ranks_on_one_gpu": bool(one_device and world > 1),
+                   "multi_gpu_status": "the builder had one GPU: the RCCL int32 all-reduce is validated on a single rank "
+                                       "(tests/test_gpu_rccl_single.py) and the sharding on gloo (world 2 / 3); N > 1 on real "
+                                       "GPUs first runs in the driver's SCALE pass",
                    "per_kernel_hip_events_in_timed_region": not args.no_profile},
         "tr_queries_per_s": C_total * args.steps / dt,
         "hits_checksum": int(hits.sum().item()),
@@ -404,12 +408,14 @@ def main():
             all_ms = sum(v["ms"] for v in convs.values())
             all_fl = sum(v["flops"] for v in convs.values())
             traffic, tsrc = None, None
-            try:            # HBM bytes per launch of this kernel from the committed rocprofv3 PMC passes (same chunk size)
-                pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))["kernels"].get(name)
-                if pm and pm["images_per_launch"] == args.chunk:
-                    traffic, tsrc = pm["hbm_bytes_corrected"], "profiles/r01_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE, WRITE_SIZE)"
-            except Exception:
-                pass
+            for tfile in ("r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+                try:        # HBM bytes per launch of this kernel from the committed rocprofv3 PMC passes (same chunk size)
+                    pm = json.load(open(os.path.join(ROOT, "profiles", tfile)))["kernels"].get(name)
+                    if pm and pm["images_per_launch"] == args.chunk:
+                        traffic, tsrc = pm["hbm_bytes_corrected"], "profiles/%s (rocprofv3 --pmc FETCH_SIZE, WRITE_SIZE)" % tfile
+                        break
+                except Exception:
+                    pass
             out["roofline"] = {"bound": "mfma", "kernel": name, "achieved": ach, "peak": PEAK_F32_MFMA, "unit": "TFLOP/s",
                                "frac": ach / PEAK_F32_MFMA, "traffic": traffic, "traffic_source": tsrc,
                                "launches": d["launches"], "avg_launch_ms": d["ms"] / d["launches"],
@@ -420,10 +426,13 @@ def main():
         if w and w["ms"] > 0:
             gbs = w["bytes"] / (w["ms"] * 1e-3) / 1e9
             wtr = None
-            try:
-                wtr = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))["kernels"].get("k_warp_net")
-            except Exception:
-                pass
+            for tfile in ("r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+                try:
+                    wtr = json.load(open(os.path.join(ROOT, "profiles", tfile)))["kernels"].get("k_warp_net")
+                    if wtr:
+                        break
+                except Exception:
+                    pass
             out["warp_roofline"] = {"bound": "hbm", "kernel": "k_warp_net", "achieved": gbs, "peak": PEAK_HBM, "unit": "GB/s",
                                     "frac": gbs / PEAK_HBM, "traffic": wtr["hbm_bytes_corrected"] if wtr else None,
                                     "traffic_images_per_launch": wtr["images_per_launch"] if wtr else None,

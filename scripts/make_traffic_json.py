@@ -45,7 +45,7 @@ def label(k):
 res = {"note": __doc__.strip().replace("\n", " "), "kernels": {}}
 for wl, images in (("gtsrb", 32000), ("trhits", 8000), ("wrn", 1024)):
     fe, wr, sq = load("fetch_" + wl), load("write_" + wl), load("sq_" + wl)
-    tcc, tcp = load("tcc_" + wl), load("tcp_" + wl)
+    tcc, tcp, ta = load("tcc_" + wl), load("tcp_" + wl), load("ta_" + wl)
     for k in fe:
         name = label(k)
         if not name or (wl == "trhits" and name.startswith("k_conv")):
@@ -66,6 +66,9 @@ for wl, images in (("gtsrb", 32000), ("trhits", 8000), ("wrn", 1024)):
         if k in tcp:
             e["tcp_tcc_read_req"] = tcp[k].get("TCP_TCC_READ_REQ_sum")
             e["l2_to_l1_bytes_at_64B_per_req"] = 64.0 * e["tcp_tcc_read_req"] if e["tcp_tcc_read_req"] else None
+        if k in ta:
+            e["ta_busy_sum"], e["grbm_gui_active"] = ta[k].get("TA_TA_BUSY_sum"), ta[k].get("GRBM_GUI_ACTIVE")
+            e["ta_flat_read_wavefronts"] = ta[k].get("TA_FLAT_READ_WAVEFRONTS_sum")
         res["kernels"][name] = e
 out = os.path.join(ROOT, "profiles", tag + "_pmc_traffic.json")
 json.dump(res, open(out, "w"), indent=1)

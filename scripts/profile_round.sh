@@ -20,6 +20,11 @@ pass fetch_trhits "FETCH_SIZE" $R/scripts/prof_tr_hits.py || exit 4
 pass write_trhits "WRITE_SIZE" $R/scripts/prof_tr_hits.py || exit 5
 pass tcc_trhits "TCC_HIT_sum TCC_MISS_sum" $R/scripts/prof_tr_hits.py || echo non-fatal
 pass tcp_trhits "TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum" $R/scripts/prof_tr_hits.py || echo non-fatal
+pass ta_trhits "TA_TA_BUSY_sum TA_FLAT_READ_WAVEFRONTS_sum GRBM_GUI_ACTIVE" $R/scripts/prof_tr_hits.py || echo non-fatal
+pass sqv_trhits "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_BUSY_CYCLES" $R/scripts/prof_tr_hits.py || echo non-fatal
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/bf16 -o bf16 -- python3 $R/scripts/tune_bf16.py 32000 3 > $O/bf16_under_rocprof.log 2> $O/bf16.err || echo non-fatal
+rm -f $O/bf16/*kernel_trace.csv
+pass sq_bf16 "SQ_BUSY_CYCLES SQ_WAVES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE" $R/scripts/tune_bf16.py 32000 2 || echo non-fatal
 pass fetch_wrn "FETCH_SIZE" $R/scripts/tune_wrn.py 1024 || exit 6
 pass write_wrn "WRITE_SIZE" $R/scripts/tune_wrn.py 1024 || exit 7
 pass sq_wrn "SQ_BUSY_CYCLES SQ_WAVES SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_VALU_MFMA_BUSY_CYCLES" $R/scripts/tune_wrn.py 1024 || echo non-fatal
