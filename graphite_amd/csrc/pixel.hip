@@ -484,6 +484,182 @@ __global__ __launch_bounds__(256) void k_warp_net32(const float* __restrict__ at
 }
 
 // ---------------------------------------------------------------------------------------------
+// Quad-gather warp (the default for launches whose transforms are all separable).
+// k_warp_net32 gives a lane one OUTPUT pixel and lets it fetch its 16 texels in 16 instructions: in each of them the 64
+// lanes read 64 different 128-byte lines (the source columns of neighbouring output pixels are ~122 bytes apart), and the
+// texture path looks lines up about one per clock -- 64 clocks per instruction, 16.4 K clocks per image, TA busy 90 %
+// (profiles/r02_final_pmc_ta_trhits.csv).  Here a lane is one TEXEL COLUMN of one warped pixel: the four lanes of a quad
+// hold (warped column 2*ox, source column sx0 / sx1) and (2*ox+1, sx0 / sx1) -- 80-odd contiguous bytes of one source
+// row -- and a wavefront covers 16 neighbouring output pixels, so that one load instruction reads one contiguous ~2 KB run
+// of a source row (16-17 lines instead of 64).  Each lane fetches the top and the bottom texel of its column for both
+// warped rows (4 loads), multiplies by its own weights and the lane pair adds the products up over DPP in the order of
+// warp_gamma_rgbx -- ((a*w0 + b*w1) + c*w2) + d*w3, float addition being commutative --, the even lane applies the gamma
+// table, quad lane 0 fetches the neighbouring warped column's value over DPP and finishes the pixel.
+// The row coordinates (the f64 part: Y of each of the 64 x 64 warped pixels) are worked out once per image into LDS.
+// Arithmetic: k_warp_net32's separable path, value for value.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float dpp_pair_swap(float v) {          // quad_perm [1,0,3,2]
+    return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0xB1, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float dpp_quad_lane2(float v) {         // quad_perm [2,2,2,2]
+    return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0xAA, 0xf, 0xf, true));
+}
+
+template <int OUT>
+__global__ __launch_bounds__(256) void k_warp_quad(const float* __restrict__ att_all, int H, int W, int nslots,
+                                                   const XformDev* __restrict__ xf, int T, long long n_begin, int cand0,
+                                                   int normalize, int count, int xcd_map, const float* __restrict__ c11,
+                                                   float* __restrict__ out) {
+    constexpr int net = 32;
+    __shared__ float s_lutf[256];
+    __shared__ WarpCol s_col[64];
+    __shared__ Tap s_tx[32], s_ty[32];
+    __shared__ float s_c11[12];
+    __shared__ int s_row[64 * 64];                // [warped row 2*oy + jy][warped column 2*ox + jx]: r0 | fy5 << 16 | (r1 - r0) << 21
+    const int local = warp_local_index(count, xcd_map);
+    if (local >= count) return;                   // uniform for the workgroup
+    const long long n = n_begin + local;
+    const int cand = (int)(n / T) - cand0, t = (int)(n % T);
+    const XformDev* x = xf + t;
+    const int tid = threadIdx.x;
+    const int cw = x->crop_x, ch = x->crop_y, bw0 = x->bw0;
+    const bool same = (cw == net && ch == net);
+    const bool area2 = (cw == 2 * net && ch == 2 * net);
+    const double scx = 1.0 / ((double)net / (double)cw), scy = 1.0 / ((double)net / (double)ch);
+    s_lutf[tid] = clamp01((float)((double)x->lut[tid] / 255.0));
+    if (OUT == GR_OUT_NHWC4_C11 && tid >= 96 && tid < 108) s_c11[tid - 96] = c11[tid - 96];
+    if (tid >= 64 && tid < 96) {
+        const int o = tid - 64;
+        Tap tx, ty;
+        if (same) { tx.i0 = tx.i1 = ty.i0 = ty.i1 = o; tx.w0 = ty.w0 = 1.f; tx.w1 = ty.w1 = 0.f; }
+        else { tx = tap_h(o, cw, scx); ty = tap_v(o, ch, scy); }
+        s_tx[o] = tx; s_ty[o] = ty;
+    }
+    if (tid < 64) {                               // warped column (tid & 1 ? i1 : i0) of output column tid >> 1, as k_warp_net32
+        const int ox = tid >> 1;
+        int xc;
+        if (same) xc = ox;
+        else { Tap tx = tap_h(ox, cw, scx); xc = (tid & 1) ? tx.i1 : tx.i0; }
+        const double m0 = x->Mi[0], m2 = x->Mi[2], m3 = x->Mi[3], m6 = x->Mi[6], m8 = x->Mi[8];
+        const int xb = (xc / bw0) * bw0, x1 = xc - xb;
+        const double X0 = m0 * xb + m2;
+        const double W0 = m6 * xb + m8;
+        double Wd = W0 + m6 * x1;
+        Wd = 32.0 * (Wd != 0.0 ? 1.0 / Wd : 0.0);
+        const int X = cv_round_sat((X0 + m0 * x1) * Wd);
+        const int sx = sat_short(X >> 5);
+        WarpCol c;
+        c.Wd = Wd; c.A = m3 * xb; c.B = m3 * x1;
+        c.sx0 = clipi(sx, 0, W); c.sx1 = clipi(sx + 1, 0, W);
+        c.fx = (float)(X & 31) * (1.f / 32.f);
+        c.pad_ = 0;
+        s_col[tid] = c;
+    }
+    __syncthreads();
+    {                                             // row table: thread = warped column tid & 63, 16 of the 64 warped rows
+        const int k = tid & 63;
+        const double cA = s_col[k].A, cB = s_col[k].B, cWd = s_col[k].Wd;
+        const double m4 = x->Mi[4], m5 = x->Mi[5];
+#pragma unroll 4
+        for (int i = 0; i < 16; i++) {
+            const int m = (tid >> 6) + 4 * i;
+            const Tap ty = s_ty[m >> 1];
+            const int yr = (m & 1) ? ty.i1 : ty.i0;
+            const double my = m4 * yr;
+            const double Y0 = (cA + my) + m5;
+            const int Y = cv_round_sat((Y0 + cB) * cWd);
+            const int sy = sat_short(Y >> 5);
+            const int r0 = clipi(sy, 0, H), r1 = clipi(sy + 1, 0, H);
+            s_row[m * 64 + k] = r0 | ((Y & 31) << 16) | ((r1 - r0) << 21);
+        }
+    }
+    __syncthreads();
+    const size_t pl = (size_t)H * W;
+    const char* att = reinterpret_cast<const char*>(att_all) + ((size_t)cand * nslots + x->slot) * pl * 16;
+    const unsigned Wb = (unsigned)W * 16u;        // 32-bit byte offsets from a uniform base (the launcher checks the frame size)
+    const int lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int hh = lane & 1, jx = (lane >> 1) & 1;
+    const int ox = (wv & 1) * 16 + (lane >> 2);
+    const int k = 2 * ox + jx;
+    const unsigned sxb = 16u * (unsigned)(hh ? s_col[k].sx1 : s_col[k].sx0);
+    const float fx = s_col[k].fx;
+    const float wx = hh ? fx : 1.f - fx;
+    const Tap tx = s_tx[ox];
+#pragma unroll 2
+    for (int i = 0; i < 16; i++) {
+        const int oy = (wv >> 1) + 2 * i;
+        const Tap ty = s_ty[oy];
+        float g[2][3];
+        float4 tt[2], tb[2];
+        float wt[2], wb[2];
+#pragma unroll
+        for (int jy = 0; jy < 2; jy++) {
+            const int e = s_row[(2 * oy + jy) * 64 + k];
+            const unsigned ot = __umul24((unsigned)e & 0xffffu, Wb) + sxb;
+            const unsigned ob = ot + ((e >> 21) ? Wb : 0u);
+            const float fy = (float)((e >> 16) & 31) * (1.f / 32.f);
+            wt[jy] = (1.f - fy) * wx;             // w0 (even lane) / w1 (odd lane)
+            wb[jy] = fy * wx;                     // w2 / w3
+            tt[jy] = *reinterpret_cast<const float4*>(att + ot);
+            tb[jy] = *reinterpret_cast<const float4*>(att + ob);
+        }
+#pragma unroll
+        for (int jy = 0; jy < 2; jy++) {
+            const float pt[3] = {tt[jy].x * wt[jy], tt[jy].y * wt[jy], tt[jy].z * wt[jy]};
+            const float pb[3] = {tb[jy].x * wb[jy], tb[jy].y * wb[jy], tb[jy].z * wb[jy]};
+#pragma unroll
+            for (int c = 0; c < 3; c++) {
+                float sacc = pt[c] + dpp_pair_swap(pt[c]);
+                sacc = sacc + pb[c];
+                sacc = sacc + dpp_pair_swap(pb[c]);
+                g[jy][c] = gamma_stage_f(sacc, s_lutf);   // the even lane's value is the warped pixel; odd lanes are ignored
+            }
+        }
+        float v[3];
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            const float g00 = g[0][c], g10 = g[1][c];
+            const float g01 = dpp_quad_lane2(g00), g11 = dpp_quad_lane2(g10);
+            float r;
+            if (same) r = g00;
+            else if (area2) r = ((((0.f + g00) + g01) + g10) + g11) * 0.25f;
+            else {
+                const float h0 = g00 * tx.w0 + g01 * tx.w1;
+                const float h1 = g10 * tx.w0 + g11 * tx.w1;
+                r = h0 * ty.w0 + h1 * ty.w1;
+            }
+            r = clamp01(r);
+            v[c] = normalize ? r - 0.5f : r;
+        }
+        if ((lane & 3) == 0) {
+            const int p = oy * net + ox;
+            if (OUT == GR_OUT_CHW) {
+                float* o = out + (size_t)local * 3 * net * net;
+                for (int c = 0; c < 3; c++) o[c * net * net + p] = v[c];
+            } else {
+                float4 o4;
+                if (OUT == GR_OUT_NHWC4_C11) {
+                    float r[3];
+#pragma unroll
+                    for (int kk = 0; kk < 3; kk++) {
+                        float a = 0.f;
+                        a = fmaf(v[0], s_c11[kk * 3 + 0], a);
+                        a = fmaf(v[1], s_c11[kk * 3 + 1], a);
+                        a = fmaf(v[2], s_c11[kk * 3 + 2], a);
+                        a = a + s_c11[9 + kk];
+                        r[kk] = a > 0.f ? a : 0.f;
+                    }
+                    o4 = make_float4(r[0], r[1], r[2], 0.f);
+                } else {
+                    o4 = make_float4(v[0], v[1], v[2], 0.f);
+                }
+                reinterpret_cast<float4*>(out)[(size_t)local * (net * net) + p] = o4;
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // LDS-band warp: the north star's "LDS-staged source tiles".  OPT-IN (GRAPHITE_WARP_BAND=1): correct, bit-identical to
 // k_warp_net32, and slower than it on MI355X -- kept as the measured alternative (profiles/r02_warp_kernels.md).
 //
@@ -895,11 +1071,19 @@ int px_warp_net(gr_ctx* ctx, const float* att, int H, int W, const gr_xforms* xf
                            (long long)n_begin, cand0, normalize, net, var_stride > 0 ? 1 : 0,
                            (long long)(var_stride > 0 ? var_stride : (int64_t)3 * net * net), count, use_map, out);
     } else {
-#define WN(M) hipLaunchKernelGGL(k_warp_net32<M>, dim3(grid), dim3(256), 0, st, att, H, W, xf->nslots, xf->dev, xf->T, \
-                                 (long long)n_begin, cand0, normalize, count, use_map, c11, out)
-        if (out_mode == GR_OUT_CHW) WN(GR_OUT_CHW);
-        else if (out_mode == GR_OUT_NHWC4) WN(GR_OUT_NHWC4);
-        else WN(GR_OUT_NHWC4_C11);
+        static int quad = -1;                    // GRAPHITE_WARP_QUAD=0: the one-lane-per-output-pixel kernel (A/B runs)
+        if (quad < 0) { const char* e = getenv("GRAPHITE_WARP_QUAD"); quad = (e && e[0] == '0') ? 0 : 1; }
+#define WN(K, M) hipLaunchKernelGGL(K<M>, dim3(grid), dim3(256), 0, st, att, H, W, xf->nslots, xf->dev, xf->T, \
+                                    (long long)n_begin, cand0, normalize, count, use_map, c11, out)
+        if (quad && xf->all_sep && H <= 32768 && W <= (1 << 19) && (long long)H * W * 16 <= 0xffffffffLL) {   // row table packs a source row in 16 bits
+            if (out_mode == GR_OUT_CHW) WN(k_warp_quad, GR_OUT_CHW);
+            else if (out_mode == GR_OUT_NHWC4) WN(k_warp_quad, GR_OUT_NHWC4);
+            else WN(k_warp_quad, GR_OUT_NHWC4_C11);
+        } else {
+            if (out_mode == GR_OUT_CHW) WN(k_warp_net32, GR_OUT_CHW);
+            else if (out_mode == GR_OUT_NHWC4) WN(k_warp_net32, GR_OUT_NHWC4);
+            else WN(k_warp_net32, GR_OUT_NHWC4_C11);
+        }
 #undef WN
     }
     GR_HIP(ctx, hipGetLastError());
