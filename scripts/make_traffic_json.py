@@ -35,7 +35,7 @@ def label(k):
     m = re.match(r"void k_conv_halo_cc<3, 32, (\d+), (\d+), (\d+)", k)
     if m:
         return "k_conv_halo_cc<tile %sx%s x%s images>" % m.groups()
-    if "k_warp_net" in k:
+    if "k_warp_net" in k or "k_warp_quad" in k:
         return "k_warp_net"
     if "k_composite" in k:
         return "k_composite"
