@@ -46,6 +46,7 @@ struct HaloBfParams {
     const float* bias;      // [COUT]
     void* out;              // [B,H,W,COUT] or pooled [B,H/2,W/2,COUT], f32 or bf16 (OUT_BF)
     int B, H, W, relu;
+    int dbg;                // tuning aid (GRAPHITE_BF_DBG, scripts/bf16_phases.sh): 1 = skip the tile staging, 2 = skip the MFMA loop, 4 = skip the epilogue (wrong results)
 };
 
 // geometry shared by the kernel and its launcher
@@ -149,6 +150,7 @@ void k_conv_halo_bf16(HaloBfParams p) {
         int px = tid / SEG;
         int hx = px % TWH, hy = (px / TWH) % THH, im = px / (TWH * THH);
         const u32x4* src = reinterpret_cast<const u32x4*>(p.in) + seg;
+        if (!(p.dbg & 1))
 #pragma unroll
         for (int it0 = 0; it0 < IT; it0 += UB) {
             u32x4 v[UB];
@@ -242,6 +244,7 @@ void k_conv_halo_bf16(HaloBfParams p) {
     // iteration s: MFMAs of stage s from LDS buffer s&1; stage s+1 leaves its registers for the other buffer (last read
     // in iteration s-1, before the previous barrier) and those registers take the loads of stage s+PF+2
     // (a compile-time loop: with run-time slot indices the register ring ends up in scratch memory)
+    if (!(p.dbg & 2))
     bf_static_for<NS>([&](auto sc) {
         constexpr int s = decltype(sc)::value;
         constexpr int slot = (s + 1) % (PF + 1);
@@ -256,7 +259,7 @@ void k_conv_halo_bf16(HaloBfParams p) {
     // one 2- or 4-byte access per value (16 per tile and lane), and a store costs the wave about as much as three MFMAs.
     // Each tile therefore goes through a wave-private LDS patch (the loop's last barrier has retired every read of the
     // input tile and of the weight buffers) and leaves as 16-byte stores: 8 bf16 (or 4 f32) channels of one pixel per lane.
-    {
+    if (!(p.dbg & 4)) {
         constexpr int EROW = 144;                        // bytes per patch row: 32 channels x 4 B + 16 (9 slots, odd)
         static_assert(NT / 64 * 32 * EROW <= G::LDS_BYTES, "epilogue patches must fit the kernel's LDS");
         unsigned char* patch = smem_bf + wave * (32 * EROW);

@@ -685,6 +685,7 @@ static int run_gtsrb_halo_bf16(gr_ctx* ctx, const Layer& L, int layer, const flo
                                bool in_bf = false, bool out_bf = false) {      // activations stored as bf16 (variant 0 only)
     HaloBfParams p;
     p.in = in; p.wgt = L.wbf; p.bias = L.bias; p.out = out; p.B = B; p.H = H; p.W = H; p.relu = 1;
+    { static int dbg = -1; if (dbg < 0) { const char* e = getenv("GRAPHITE_BF_DBG"); dbg = e ? atoi(e) : 0; } p.dbg = dbg; }
     const bool pool = layer == 1 || layer == 3 || layer == 5;
     const double M = (double)B * H * H;
     const double flops = 2.0 * M * L.Cout * 25 * L.CinT;
