@@ -71,7 +71,7 @@ struct HaloBfGeom {
     }
 };
 
-template <int CIN, int COUT, int TH, int TW, int NIMG, int WM, int WN, int TM, int TN, int KBS, bool POOL, int PF, bool IN_BF, bool OUT_BF>
+template <int CIN, int COUT, int TH, int TW, int NIMG, int WM, int WN, int TM, int TN, int KBS, bool POOL, int PF, bool IN_BF, bool OUT_BF, int PD>
 __global__ __launch_bounds__(WM* WN * 64, (HaloBfGeom<CIN, COUT, TH, TW, NIMG, KBS, POOL>::occ(WM * WN * 64)))
 void k_conv_halo_bf16(HaloBfParams p) {
     using G = HaloBfGeom<CIN, COUT, TH, TW, NIMG, KBS, POOL>;
@@ -216,43 +216,88 @@ void k_conv_halo_bf16(HaloBfParams p) {
             for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
 
     const int b_lane = (wn * TN) * 1024 + lane * 16;
-    auto compute = [&](int s) {
+    // Fragments of k-block g (flattened over the stages): A from the resident tile, B from LDS buffer (g / KBS) & 1.
+    auto read_a = [&](bf16x8 (&av)[TM], int g) {
+        const int s = g / KBS, kbl = g % KBS;
+        int tap, c;
+        if (KBS % KB_TAP == 0) { tap = s * (KBS / KB_TAP) + kbl / KB_TAP; c = kbl % KB_TAP; }
+        else { tap = s / (KB_TAP / KBS); c = (s % (KB_TAP / KBS)) * KBS + kbl; }
+        const int ky = tap / 5, kx = tap - 5 * ky;
+        const unsigned char* at = asm_ + ky * RSB + kx * PSB + c * 32;
+#pragma unroll
+        for (int i = 0; i < TM; i++) av[i] = *reinterpret_cast<const bf16x8*>(at + a_off[i]);
+    };
+    auto read_b = [&](bf16x8 (&bv)[TN], int g) {
+        const int s = g / KBS, kbl = g % KBS;
         const unsigned char* bb = bsm + (s & 1) * STAGE_B + b_lane;
 #pragma unroll
-        for (int kbl = 0; kbl < KBS; kbl++) {
-            int tap, c;
-            if (KBS % KB_TAP == 0) { tap = s * (KBS / KB_TAP) + kbl / KB_TAP; c = kbl % KB_TAP; }
-            else { tap = s / (KB_TAP / KBS); c = (s % (KB_TAP / KBS)) * KBS + kbl; }
-            const int ky = tap / 5, kx = tap - 5 * ky;
-            const unsigned char* at = asm_ + ky * RSB + kx * PSB + c * 32;
-            bf16x8 av[TM], bv[TN];
-#pragma unroll
-            for (int i = 0; i < TM; i++) av[i] = *reinterpret_cast<const bf16x8*>(at + a_off[i]);
-#pragma unroll
-            for (int j = 0; j < TN; j++) bv[j] = *reinterpret_cast<const bf16x8*>(bb + (kbl * NTILE + j) * 1024);
-#pragma unroll
-            for (int i = 0; i < TM; i++)
-#pragma unroll
-                for (int j = 0; j < TN; j++)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[i], bv[j], acc[i][j], 0, 0, 0);
-        }
+        for (int j = 0; j < TN; j++) bv[j] = *reinterpret_cast<const bf16x8*>(bb + (kbl * NTILE + j) * 1024);
     };
 
     lstore(breg[0], 0);
     gload(breg[0], PF + 1);
     __syncthreads();                                     // tile + weight stage 0 staged
-    // iteration s: MFMAs of stage s from LDS buffer s&1; stage s+1 leaves its registers for the other buffer (last read
-    // in iteration s-1, before the previous barrier) and those registers take the loads of stage s+PF+2
-    // (a compile-time loop: with run-time slot indices the register ring ends up in scratch memory)
-    if (!(p.dbg & 2))
-    bf_static_for<NS>([&](auto sc) {
-        constexpr int s = decltype(sc)::value;
-        constexpr int slot = (s + 1) % (PF + 1);
-        compute(s);
-        lstore(breg[slot], (s + 1) & 1);
-        gload(breg[slot], s + PF + 2);
-        __syncthreads();
-    });
+    // The k loop, flattened over the stages and unrolled at compile time.  Fragments are read PD k-blocks ahead of the
+    // MFMAs that use them (PD + 1 register sets): left to itself the compiler reads a k-block's fragments, waits for all of
+    // them and only then issues its MFMAs.  A fragments come from the resident tile and are read ahead across a stage
+    // boundary too; B fragments of a new stage can only be read after its barrier.
+    // Stage boundary after the last k-block of stage s: stage s+1 leaves its registers for the other LDS buffer (last read
+    // in stage s-1, before the previous barrier) and those registers take the loads of stage s+PF+2.
+    static_assert(PD >= 0 && PD <= KBS, "read-ahead distance");
+    constexpr int NSET = PD + 1;
+    bf16x8 fa[NSET][TM], fb[NSET][TN];
+    if constexpr (PD == 0) {                             // no read-ahead: the compiler's own schedule (conv4_2: one workgroup
+        if (!(p.dbg & 2))                                // of 112 KB per CU, measured 4 % faster this way)
+        bf_static_for<NS>([&](auto sc) {
+            constexpr int s = decltype(sc)::value;
+            constexpr int slot = (s + 1) % (PF + 1);
+#pragma unroll
+            for (int kbl = 0; kbl < KBS; kbl++) {
+                read_a(fa[0], s * KBS + kbl);
+                read_b(fb[0], s * KBS + kbl);
+#pragma unroll
+                for (int i = 0; i < TM; i++)
+#pragma unroll
+                    for (int j = 0; j < TN; j++)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[0][i], fb[0][j], acc[i][j], 0, 0, 0);
+            }
+            lstore(breg[slot], (s + 1) & 1);
+            gload(breg[slot], s + PF + 2);
+            __syncthreads();
+        });
+    } else if (!(p.dbg & 2)) {
+        bf_static_for<PD>([&](auto dc) {
+            constexpr int d = decltype(dc)::value;
+            if constexpr (d < NKB) { read_a(fa[d % NSET], d); read_b(fb[d % NSET], d); }   // PD <= KBS: all in stage 0
+        });
+        bf_static_for<NKB>([&](auto gc) {
+            constexpr int g = decltype(gc)::value;
+            constexpr int cur = g % NSET;
+            constexpr int s = g / KBS;
+            constexpr bool last_of_stage = (g % KBS) == KBS - 1;
+            if constexpr (g + PD < NKB) {
+                read_a(fa[(g + PD) % NSET], g + PD);
+                if constexpr ((g + PD) / KBS == s) read_b(fb[(g + PD) % NSET], g + PD);
+            }
+#pragma unroll
+            for (int i = 0; i < TM; i++)
+#pragma unroll
+                for (int j = 0; j < TN; j++)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[cur][i], fb[cur][j], acc[i][j], 0, 0, 0);
+            if constexpr (last_of_stage) {
+                constexpr int slot = (s + 1) % (PF + 1);
+                lstore(breg[slot], (s + 1) & 1);
+                gload(breg[slot], s + PF + 2);
+                __syncthreads();
+                // B fragments of the new stage that the read-ahead had to leave out
+                bf_static_for<PD>([&](auto dc) {
+                    constexpr int g2 = g + 1 + decltype(dc)::value;
+                    if constexpr (g2 < NKB && g2 / KBS == s + 1 && g2 <= g + PD) read_b(fb[g2 % NSET], g2);
+                });
+            }
+            __builtin_amdgcn_sched_barrier(0);           // keep the read-ahead where it is written, not next to its use
+        });
+    }
 
     // ---- epilogue: + bias, ReLU, optional 2x2 max-pool, NHWC store ----
     // An accumulator tile has its 32 output channels on the lanes and its pixels in the registers: stored directly that is
@@ -345,13 +390,13 @@ void k_conv_halo_bf16(HaloBfParams p) {
 }
 
 template <int CIN, int COUT, int TH, int TW, int NIMG, int WM, int WN, int TM, int TN, int KBS, bool POOL, int PF = 3, bool IN_BF = false,
-          bool OUT_BF = false>
+          bool OUT_BF = false, int PD = 2>
 static inline hipError_t launch_conv_halo_bf16(const HaloBfParams& p, hipStream_t st) {
     using G = HaloBfGeom<CIN, COUT, TH, TW, NIMG, KBS, POOL>;
     constexpr size_t smem = G::LDS_BYTES;
     static_assert(smem <= 160 * 1024, "LDS");
     if (p.H % TH || p.W % TW) return hipErrorInvalidValue;
-    auto kern = k_conv_halo_bf16<CIN, COUT, TH, TW, NIMG, WM, WN, TM, TN, KBS, POOL, PF, IN_BF, OUT_BF>;
+    auto kern = k_conv_halo_bf16<CIN, COUT, TH, TW, NIMG, WM, WN, TM, TN, KBS, POOL, PF, IN_BF, OUT_BF, PD>;
     static bool attr_set[64] = {false};                  // the attribute is per device
     int dev_ = 0;
     if (hipGetDevice(&dev_) != hipSuccess || dev_ < 0 || dev_ >= 64) return hipErrorInvalidDevice;

@@ -697,22 +697,51 @@ static int run_gtsrb_halo_bf16(gr_ctx* ctx, const Layer& L, int layer, const flo
     const int v = bf16_variant(layer);
     //                                 CIN COUT  TH  TW NIMG WM WN TM TN KBS POOL
 #define HB(...) e = launch_conv_halo_bf16<__VA_ARGS__>(p, st)
-    if (in_bf || out_bf) {              // variant 0 of conv4_1 / conv4_2 with bf16 activations on either side
-#define HB4(...)                                                                                                   \
+    if (in_bf && out_bf && v != 0) {    // tuning variants of the production configuration (every link bf16)
+#define HBB(...) HB(__VA_ARGS__, 3, true, true)
+#define HBP(PD, ...) HB(__VA_ARGS__, 3, true, true, PD)
+        switch (layer * 8 + v) {
+        case 1 * 8 + 1: HBB( 32,  32,  8, 32, 1,  4, 1, 2, 1,  2, true ); break;
+        case 1 * 8 + 2: HBB( 32,  32, 16, 32, 1,  8, 1, 2, 1,  2, true ); break;
+        case 1 * 8 + 3: HBB( 32,  32, 16, 32, 1,  4, 1, 4, 1, 10, true ); break;
+        case 1 * 8 + 4: HBB( 32,  32,  8, 32, 1,  4, 1, 2, 1, 10, true ); break;
+        case 2 * 8 + 1: HBB( 32,  64, 16, 16, 1,  4, 2, 2, 1,  2, false); break;
+        case 2 * 8 + 2: HBB( 32,  64, 16, 16, 1,  2, 2, 4, 1, 10, false); break;
+        case 2 * 8 + 3: HBB( 32,  64, 16, 16, 1,  2, 1, 4, 2,  2, false); break;
+        case 2 * 8 + 4: HBB( 32,  64, 16, 16, 1,  4, 1, 2, 2,  2, false); break;
+        case 3 * 8 + 1: HBB( 64,  64, 16, 16, 1,  4, 2, 2, 1, 20, true ); break;
+        case 3 * 8 + 2: HBB( 64,  64, 16, 16, 1,  4, 1, 2, 2,  4, true ); break;
+        case 3 * 8 + 3: HBB( 64,  64, 16, 16, 1,  2, 2, 4, 1,  4, true ); break;
+        case 3 * 8 + 4: HBB( 64,  64, 16, 16, 1,  2, 1, 4, 2,  4, true ); break;
+        case 4 * 8 + 1: HBB( 64, 128,  8,  8, 2,  2, 4, 2, 1,  2, false); break;
+        case 4 * 8 + 2: HBB( 64, 128,  8,  8, 2,  2, 2, 2, 2,  4, false); break;
+        case 4 * 8 + 3: HBB( 64, 128,  8,  8, 2,  1, 4, 4, 1,  4, false); break;
+        case 5 * 8 + 1: HBP(2, 128, 128,  8,  8, 2,  2, 4, 2, 1,  4, true ); break;
+        case 5 * 8 + 2: HBB(128, 128,  8,  8, 2,  2, 4, 2, 1,  8, true ); break;
+        case 5 * 8 + 3: HBB(128, 128,  8,  8, 2,  2, 2, 2, 2,  4, true ); break;
+        case 5 * 8 + 4: HBB(128, 128,  8,  8, 2,  1, 4, 4, 1,  4, true ); break;
+        default: return gr_fail(ctx, GR_EINVAL, "conv_halo_bf16: no variant %d for layer %d with bf16 links", v, layer);
+        }
+#undef HBB
+#undef HBP
+    } else if (in_bf || out_bf) {       // variant 0 with bf16 activations on either side
+#define HB4P(PD, ...)                                                                                              \
         do {                                                                                                       \
-            if (in_bf && out_bf) HB(__VA_ARGS__, 3, true, true);                                                   \
-            else if (in_bf) HB(__VA_ARGS__, 3, true, false);                                                       \
-            else HB(__VA_ARGS__, 3, false, true);                                                                  \
+            if (in_bf && out_bf) HB(__VA_ARGS__, 3, true, true, PD);                                               \
+            else if (in_bf) HB(__VA_ARGS__, 3, true, false, PD);                                                   \
+            else HB(__VA_ARGS__, 3, false, true, PD);                                                              \
         } while (0)
+#define HB4(...) HB4P(2, __VA_ARGS__)
         switch (layer) {
         case 1: HB4( 32,  32, 16, 32, 1,  8, 1, 2, 1, 10, true ); break;
         case 2: HB4( 32,  64, 16, 16, 1,  2, 2, 4, 1,  2, false); break;
         case 3: HB4( 64,  64, 16, 16, 1,  4, 2, 2, 1,  4, true ); break;
         case 4: HB4( 64, 128,  8,  8, 2,  2, 4, 2, 1,  4, false); break;
-        case 5: HB4(128, 128,  8,  8, 2,  2, 4, 2, 1,  4, true ); break;
+        case 5: HB4P(0, 128, 128,  8,  8, 2,  2, 4, 2, 1,  4, true ); break;   // fragment read-ahead measured slower here
         default: return gr_fail(ctx, GR_EINVAL, "conv_halo_bf16: layer %d", layer);
         }
 #undef HB4
+#undef HB4P
     } else
     switch (layer * 8 + v) {
     // variant 0 = fastest measured (profiles/r01_bf16_tune.md): 8 wavefronts per workgroup wherever the tile allows
@@ -735,7 +764,7 @@ static int run_gtsrb_halo_bf16(gr_ctx* ctx, const Layer& L, int layer, const flo
     case 4 * 8 + 2: HB( 64, 128,  8,  8, 4,  4, 4, 2, 1,  4, false); break;
     case 4 * 8 + 3: HB( 64, 128,  8,  8, 2,  2, 2, 2, 2,  4, false); break;
     case 4 * 8 + 4: HB( 64, 128,  8,  8, 4,  4, 2, 2, 2,  4, false); break;
-    case 5 * 8 + 0: HB(128, 128,  8,  8, 2,  2, 4, 2, 1,  4, true ); break;    // conv4_2
+    case 5 * 8 + 0: HB(128, 128,  8,  8, 2,  2, 4, 2, 1,  4, true , 3, false, false, 0); break;    // conv4_2
     case 5 * 8 + 1: HB(128, 128,  8,  8, 2,  2, 4, 2, 1,  2, true ); break;
     case 5 * 8 + 3: HB(128, 128,  8,  8, 1,  1, 4, 2, 1,  4, true ); break;
     case 5 * 8 + 4: HB(128, 128,  8,  8, 2,  2, 2, 2, 2,  4, true ); break;
