@@ -10,13 +10,13 @@ follows the reference step by step.
 import torch
 
 from .evaluator import TREvaluator, make_evaluator
-from .transforms import get_transform_params, convert2Network
+from .transforms import draw_transforms, normalizes
 
 
 def boost(model, x0_large, y0, mask, target_example, target=None, beta=1, iterations=30, pt_file='images/Points/14.csv',
           num_xforms=1000, net_size=32, model_type='GTSRB', goal=None, eta=500, bt=False, budget_factor=200,
           init_theta=None, square_mask=False, early_boost_exit=False, _evaluator=None):
-    xforms = get_transform_params(num_xforms, model_type)
+    xforms = draw_transforms(num_xforms, model_type)       # 'PATCHGUARD': the baseline pg table (pg_boost.py:45)
     ev = make_evaluator(_evaluator, model, x0_large, xforms, pt_file, model_type, y0, target)
     query_count = 0
     x0 = ev.resize(x0_large, mask.size()[1], mask.size()[2])
@@ -119,7 +119,8 @@ def boost(model, x0_large, y0, mask, target_example, target=None, beta=1, iterat
             break
     assert carried is None, "a speculated direction batch was left unused"
 
-    adv_example = ev.add_noise(x0_large, mask, 1.0, best_theta, clip=(model_type == 'GTSRB'))
+    # boost.py:180-183 clips for GTSRB only; pg_boost.py:201-204 clips for its (CIFAR-sized, normalised) family
+    adv_example = ev.add_noise(x0_large, mask, 1.0, best_theta, clip=normalizes(model_type))
     mask_large = ev.resize(mask, x0_large.size()[1], x0_large.size()[2])
     perturb = torch.where(mask_large > 0.0, adv_example, torch.ones(adv_example.size()))
     print("final iters_taken: ", iters_taken)

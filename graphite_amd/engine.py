@@ -14,7 +14,7 @@ import numpy as np
 import torch
 
 from . import _hip
-from .transforms import build_xform_table, XFORM_DTYPE
+from .transforms import build_xform_table, normalizes, XFORM_DTYPE
 
 
 def shard_range(total, rank, world):
@@ -105,7 +105,7 @@ def tr_hits(model, image, masks, thetas, transforms, target, pt_file='inputs/GTS
     keep = {}
 
     def eval_slice(begin, count):
-        hits, preds, _ = _hip.tr_hits_dev(hip_model, img, m, t, xf, float(lbd), model_type == 'GTSRB', int(target),
+        hits, preds, _ = _hip.tr_hits_dev(hip_model, img, m, t, xf, float(lbd), normalizes(model_type), int(target),
                                           begin, count, want_preds=return_preds)
         keep["preds"] = preds
         return hits

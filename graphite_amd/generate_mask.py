@@ -26,7 +26,7 @@ import torch
 from . import parsearguments
 from .coarse_reduction import get_coarse_reduced_mask
 from .evaluator import TREvaluator, make_evaluator
-from .transforms import get_transform_params
+from .transforms import draw_transforms
 
 scoremod = None
 FINE_WINDOW = 32          # largest speculative window (candidates per launch) in the fine reduction
@@ -84,7 +84,7 @@ def generate_mask(model, img_v_small, img_v, lbl_v, mask, img_t_small, img_t, lb
     args = _args or parsearguments.getarguments()
 
     print("Calculating Heatmap...")
-    xforms = get_transform_params(num_xforms, model_type)
+    xforms = draw_transforms(num_xforms, model_type)      # 'PATCHGUARD': the baseline pg table (pg_generate_mask.py:43)
     ev = make_evaluator(_evaluator, model, img_v, xforms, pt_file, model_type, lbl_v, lbl_t)
     query_count = 0
     object_size = mask.sum() / 3
@@ -133,15 +133,22 @@ def generate_mask(model, img_v_small, img_v, lbl_v, mask, img_t_small, img_t, lb
 
     print("Starting fine grained reduction")
     if max_mask_size > 0:
+        # generate_mask.py:117-126: every pass works on COPIES of the patch list, lbd grows by 5, the passes' queries add up.
+        # pg_generate_mask.py:119-131 (the older twin the PatchGuard driver kept): the passes share ONE list, which the
+        # first pass consumes; lbd grows by 2.5; only the last pass's queries are reported.
+        pg = model_type == 'PATCHGUARD'
         lbd = 5
         reduction_query_ct = 0
         while best_mask.sum() / 3 > max_mask_size:
+            if pg and not patches and reduction_query_ct:
+                break        # the reference would spin here for ever: its shared list is empty and the mask cannot shrink
             best_score, best_tr, best_mask, this_ct = get_fine_reduced_mask(
-                best_mask, object_size, list(patches), list(indices), img_v, img_t_small, lbl_v, lbl_t, model, xforms,
+                best_mask, object_size, patches if pg else list(patches), indices if pg else list(indices), img_v,
+                img_t_small, lbl_v, lbl_t, model, xforms,
                 pt_file, net_size, err_threshold=FINE_REJECT_THRESHOLD, HEATMAP_MODE=HEATMAP_MODE, scoremod=scoremod,
                 lbd=lbd, max_mask_size=max_mask_size, model_type=model_type, init_theta=init_theta, _evaluator=ev)
-            lbd += 5
-            reduction_query_ct += this_ct
+            lbd += 2.5 if pg else 5
+            reduction_query_ct = this_ct if pg else reduction_query_ct + this_ct
     else:
         best_score, best_tr, best_mask, reduction_query_ct = get_fine_reduced_mask(
             best_mask, object_size, patches, indices, img_v, img_t_small, lbl_v, lbl_t, model, xforms, pt_file, net_size,

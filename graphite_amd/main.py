@@ -22,7 +22,7 @@ from .evaluator import TREvaluator
 from .generate_mask import generate_mask
 from .imageio import load_image_u8_hwc, resize_u8_linear, save_image_chw
 from .models import GTSRBNet, WideResNet
-from .transforms import add_noise, get_transform_params
+from .transforms import add_noise, draw_transforms
 
 
 def _chw01(u8_hwc):
@@ -45,7 +45,8 @@ def attack_network(model, img_v, img_t, mask, lbl_v, lbl_t, pt_file, scorefile, 
     user = getpass.getuser()
     tag = (user + "_" + (image_id + "_" if image_id != '' else '') + str(lbl_v) + '_' + str(lbl_t) + '_' + str(reduceerror) +
            '_' + str(coarseerror) + '_' + str(args.coarse_mode) + '_' + scorefile + "_")
-    out_base = args.out_path + (model_type + '/' if model_type != 'GTSRB' else '')
+    # main.py:31-33: outputs/<model_type>/ except for GTSRB; main_patchguard.py:29-31 writes straight into its base directory
+    out_base = args.out_path + (model_type + '/' if model_type not in ('GTSRB', 'PATCHGUARD') else '')
 
     img_u8 = load_image_u8_hwc(img_v)
     img_torch = _chw01(img_u8)
@@ -71,7 +72,7 @@ def attack_network(model, img_v, img_t, mask, lbl_v, lbl_t, pt_file, scorefile, 
             best_theta = (tar - img_small_torch) * mask_out
             init = add_noise(img_torch, mask_out, 1.0, best_theta)
             nbits = ss ** 2
-            xforms = get_transform_params(num_xforms_mask, model_type)
+            xforms = draw_transforms(num_xforms_mask, model_type)
             ev = TREvaluator(model, img_torch, xforms, pt_file, model_type, lbl_v, lbl_t)
             success_rate, _ = ev.error(mask_out, best_theta)
             tr_score = 1 - success_rate
@@ -105,7 +106,7 @@ def attack_network(model, img_v, img_t, mask, lbl_v, lbl_t, pt_file, scorefile, 
     print("--------------------------------")
     print("Attack Completed.")
     if args.num_test_xforms > -1:
-        xforms = get_transform_params(args.num_test_xforms, model_type)
+        xforms = draw_transforms(args.num_test_xforms, model_type)
         ev = TREvaluator(model, res["adversarial"], xforms, pt_file, model_type, lbl_v, lbl_t, lbd=0.0)
         success_rate, _ = ev.error(res["mask"], torch.zeros(res["mask"].size()))
         res["final_test_tr"] = 1.0 - success_rate

@@ -92,6 +92,21 @@ def get_transform_params(num_xforms, model_type='GTSRB', nps=False, baseline=Fal
     return out
 
 
+def normalizes(model_type):
+    """Does convert2Network subtract 0.5 for this model family?  GTSRB does (transforms.py:27-29), CIFAR does not;
+    'PATCHGUARD' names the pg_transforms.py twin of the CIFAR path, which always does (pg_transforms.py:20-34)."""
+    return model_type in ('GTSRB', 'PATCHGUARD')
+
+
+def draw_transforms(num_xforms, model_type):
+    """The transform list a search driver draws for itself: get_transform_params(num_xforms, model_type)
+    (generate_mask.py:41, boost.py:23); the PatchGuard drivers draw the baseline pg table instead
+    (pg_generate_mask.py:43, pg_boost.py:45)."""
+    if model_type == 'PATCHGUARD':
+        return get_transform_params(num_xforms, 'CIFAR', baseline=True, patchguard=True)
+    return get_transform_params(num_xforms, model_type)
+
+
 def gamma_table(gamma):
     """256-entry uint8 lighting table: trunc(clip((i/255)**gamma * 255, 0, 255))  (transforms.py:70-72)."""
     # The reference evaluates Python's pow (libm) per entry and truncates.  numpy's vectorised power may differ from libm
@@ -147,9 +162,9 @@ def convert2Network(img, is_torch=True, net_size=32, model_type='GTSRB'):
     `img` is a CHW tensor (is_torch) or an HWC numpy array; returns a CHW CPU tensor."""
     from . import _hip
     x = _chw(img) if is_torch else np.ascontiguousarray(np.transpose(np.asarray(img, np.float32), (2, 0, 1)))
-    y = _hip.convert_to_network(x, net_size, model_type == 'GTSRB' and net_size == 32)
+    y = _hip.convert_to_network(x, net_size, normalizes(model_type) and net_size == 32)
     out = torch.from_numpy(y)
-    assert torch.max(out) <= (0.5 if (model_type == 'GTSRB' and net_size == 32) else 1.0)
+    assert torch.max(out) <= (0.5 if (normalizes(model_type) and net_size == 32) else 1.0)
     return out
 
 
@@ -173,7 +188,7 @@ def apply_transformation(img, mask, pert, angle, dist, gamma, blur, crop_percent
                             img_np.shape[2], img_np.shape[1], pt_file)
     if net_size != 32:
         return torch.from_numpy(_hip.transform_composited_var(img_np, mask_np, pert_np, tab, net_size)[0])
-    y = _hip.transform_composited(img_np, mask_np, pert_np, tab, net_size, model_type == 'GTSRB')
+    y = _hip.transform_composited(img_np, mask_np, pert_np, tab, net_size, normalizes(model_type))
     return torch.from_numpy(y[0])
 
 
@@ -194,7 +209,7 @@ def get_transformed_images(image, mask, transforms, lbd, theta, pt_file='inputs/
     if net_size != 32:          # :31-45: every transform has its own [3, ny, nx] (aspect of ITS crop), clamp only
         return [torch.from_numpy(a) for a in _hip.warp_batch_var(img_np, _chw(mask)[None], _chw(theta)[None], tab,
                                                                  float(lbd), net_size)]
-    out = _hip.warp_batch(img_np, _chw(mask)[None], _chw(theta)[None], tab, float(lbd), model_type == 'GTSRB',
+    out = _hip.warp_batch(img_np, _chw(mask)[None], _chw(theta)[None], tab, float(lbd), normalizes(model_type),
                           net_size)
     t = torch.from_numpy(out[0])
     return [t[i] for i in range(t.shape[0])]

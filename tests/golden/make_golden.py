@@ -296,7 +296,7 @@ def golden_binary_search():
         json.dump(rows, f)
 
 
-if __name__ == "__main__" and "--drivers" not in sys.argv:
+if __name__ == "__main__" and "--drivers" not in sys.argv and "--drivers-pg" not in sys.argv:
     xf = golden_xforms()
     golden_homography(xf)
     golden_score()
@@ -404,5 +404,103 @@ def golden_drivers():
         json.dump(rows, f)
 
 
+# ----------------------------------------------------------------- (8) PatchGuard search drivers
+class _PgModel:                                            # module level: pg_boost pickles its arguments, the model included
+    def predict(self, x):
+        return 0
+
+
+def golden_drivers_pg():
+    """The reference's patchguard/pg_generate_mask.generate_mask and pg_boost.boost, run the same way as golden_drivers():
+    transform + classify replaced by FakeTR, cv2.resize served by the CPU oracle.  32x32 frames (the CIFAR path), the
+    reference's own plain 32x32 mask, hash-generated victim / target images.  pg_boost writes ./dumped_data.pkl (a
+    debugging leftover of the reference): the drivers run inside a temporary directory."""
+    import hashlib
+    import tempfile
+    sys.path.insert(0, os.path.join(REPO, "tests"))
+    import oracle_lib as O
+    from fake_tr import FakeTR
+    from graphite_amd.imageio import load_image_chw
+    tvu = types.ModuleType("torchvision.utils")
+    tvu.save_image = _absent("torchvision.utils.save_image")
+    tv.utils = tvu
+    sys.modules["torchvision.utils"] = tvu
+
+    def cv_resize(a, dsize):
+        chw = np.ascontiguousarray(np.transpose(np.asarray(a, np.float32), (2, 0, 1)))
+        return np.ascontiguousarray(np.transpose(O.resize_linear(chw, dsize[1], dsize[0]), (1, 2, 0)))
+
+    cv2.resize = cv_resize
+    cv2.cvtColor = lambda a, code: a
+    cv2.COLOR_RGB2BGR = 0
+    import pg_generate_mask as ref_pgm
+    import pg_boost as ref_pgb
+
+    vic = torch.from_numpy(synth.synth_images("pg-victim", 1, 0.0, 1.0)[0])
+    tar = torch.from_numpy(synth.synth_images("pg-target", 1, 0.0, 1.0)[0])
+    mask = torch.from_numpy((load_image_chw(os.path.join(INP, "cifar/masks/mask.png")) * 255 > 128).astype(np.float32))
+    obj = float(mask.sum() / 3)
+    ref_dir = (tar - vic) * mask
+
+    def install(mod, fake):
+        mod.get_transformed_images = lambda img, m, xf, lbd, theta, pt_file, net_size=32, model_type='GTSRB': (m.clone(), theta.clone())
+        mod.run_predictions = lambda model, imgs, lbl_v, lbl_t=None: fake.err(imgs[0], imgs[1])
+
+    def digest(t):
+        return hashlib.sha256(np.ascontiguousarray(t.numpy()).tobytes()).hexdigest()
+
+    rows = []
+    cwd = os.getcwd()
+    with tempfile.TemporaryDirectory() as tmp:
+        os.chdir(tmp)
+        try:
+            for name, T, heat, coarse_mode, tr_lo, tr_hi, max_mask, sharp, mid in (
+                ("pg_target_binary", 100, "Target", "binary", 0.65, 0.85, -1, 6.0, 0.35),
+                ("pg_target_linear", 40, "Target", "linear", 0.5, 0.8, -1, 6.0, 0.35),
+                ("pg_target_none_maxmask", 40, "Target", "none", 0.4, 0.6, 500, 6.0, 0.2),
+                ("pg_victim_binary", 30, "Victim", "binary", 0.3, 0.6, -1, 4.0, 0.3),
+            ):
+                fake = FakeTR(T, obj, ref_dir, sharp, mid)
+                install(ref_pgm, fake)
+                install(ref_coarse, fake)
+                ref_pgm.get_coarse_reduced_mask = ref_coarse.get_coarse_reduced_mask
+                sys.argv = ["main_patchguard.py", "--coarse_mode", coarse_mode]
+                np.random.seed(42); torch.manual_seed(42)
+                import random as _r
+                _r.seed(42)
+                attacked, qc, best_mask, nbits, best_tr = ref_pgm.generate_mask(
+                    _PgModel(), vic, vic, 3, mask.clone(), tar, tar, 5, None, "score.py", heat, 1 - tr_hi, 1 - tr_lo,
+                    num_xforms=T, net_size=32, model_type='CIFAR', patch_size=4, max_mask_size=max_mask)
+                rows.append({"kind": "generate_mask", "name": name, "T": T, "heatmap": heat, "coarse_mode": coarse_mode,
+                             "tr_lo": tr_lo, "tr_hi": tr_hi, "max_mask_size": max_mask, "sharp": sharp, "mid": mid,
+                             "query_count": int(qc), "nbits": float(nbits), "best_tr": float(best_tr),
+                             "best_mask": best_mask.numpy()[0].astype(np.uint8).tolist(), "attacked_sha": digest(attacked),
+                             "fake_calls": fake.calls, "np_random_next": float(np.random.uniform()),
+                             "py_random_next": _r.random()})
+                print(name, "queries", qc, "bits", nbits, "tr", best_tr, "calls", fake.calls)
+
+            small_mask = torch.zeros(3, 32, 32)
+            small_mask[:, 8:24, 6:26] = 1
+            for name, T, bt, iters, budget in (("pg_rgf_plain", 100, False, 1000, 200), ("pg_rgf_bt", 40, True, 5, 200)):
+                fake = FakeTR(T, obj, ref_dir, 6.0, 0.1)
+                install(ref_pgb, fake)
+                ref_pgb.add_noise = ref_pg.add_noise
+                np.random.seed(42); torch.manual_seed(42)
+                adv, tr, perturb, queries, adv_small = ref_pgb.boost(
+                    _PgModel(), vic, 3, small_mask, tar, 5, beta=1, iterations=iters, pt_file=None, num_xforms=T, net_size=32,
+                    model_type='CIFAR', bt=bt, budget_factor=budget)
+                rows.append({"kind": "boost", "name": name, "T": T, "bt": bt, "iterations": iters, "budget_factor": budget,
+                             "tr": float(tr), "queries": int(queries), "adv_sha": digest(adv), "perturb_sha": digest(perturb),
+                             "adv_small_sha": digest(adv_small), "fake_calls": fake.calls,
+                             "torch_random_next": float(torch.rand(1)), "np_random_next": float(np.random.uniform())})
+                print(name, "tr", tr, "queries", queries, "calls", fake.calls)
+        finally:
+            os.chdir(cwd)
+    with open(os.path.join(HERE, "drivers_pg.json"), "w") as f:
+        json.dump(rows, f)
+
+
 if __name__ == "__main__" and "--drivers" in sys.argv:
     golden_drivers()
+if __name__ == "__main__" and "--drivers-pg" in sys.argv:
+    golden_drivers_pg()

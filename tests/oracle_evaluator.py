@@ -5,7 +5,7 @@ import torch
 
 import oracle_lib as O
 from graphite_amd import weights
-from graphite_amd.transforms import build_xform_table
+from graphite_amd.transforms import build_xform_table, normalizes
 
 
 class OracleEvaluator:
@@ -14,7 +14,7 @@ class OracleEvaluator:
         self.tensors = weights.gtsrb_tensor_list(state_dict)
         self.image = np.ascontiguousarray(image.numpy(), dtype=np.float32)
         self.tab = build_xform_table(transforms, image.shape[2], image.shape[1], pt_file)
-        self.T, self.label, self.target, self.normalize = len(transforms), label, target, model_type == 'GTSRB'
+        self.T, self.label, self.target, self.normalize = len(transforms), label, target, normalizes(model_type)
         self.nthreads = nthreads
         self.evaluated = 0
 

@@ -178,3 +178,85 @@ def test_heatmap_cache_round_trip_and_restricted_loader(scene, oracle, tmp_path)
     (tmp_path / "notaheatmap.pkl").write_bytes(pickle.dumps({"a": 1}))
     with pytest.raises(ValueError, match="not a heatmap"):
         ggm.load_heatmap(str(tmp_path / "notaheatmap.pkl"))
+
+
+# ---- the PatchGuard twins (patchguard/pg_generate_mask.py, pg_boost.py) against the reference's own, same method ----
+PG_ROWS = json.load(open(os.path.join(GOLD, "drivers_pg.json")))
+
+
+@pytest.fixture(scope="module")
+def pg_scene():
+    from graphite_amd import synth
+    vic = torch.from_numpy(synth.synth_images("pg-victim", 1, 0.0, 1.0)[0])
+    tar = torch.from_numpy(synth.synth_images("pg-target", 1, 0.0, 1.0)[0])
+    mask = torch.from_numpy((load_image_chw(os.path.join(INP, "cifar/masks/mask.png")) * 255 > 128).astype(np.float32))
+    return dict(vic=vic, tar=tar, mask=mask, obj=float(mask.sum() / 3), ref_dir=(tar - vic) * mask)
+
+
+@pytest.mark.parametrize("speculate", [True, False], ids=["speculative", "sequential"])
+@pytest.mark.parametrize("row", [r for r in PG_ROWS if r["kind"] == "generate_mask"], ids=lambda r: r["name"])
+def test_pg_generate_mask_matches_reference_driver(row, pg_scene, oracle, speculate):
+    from graphite_amd.patchguard import pg_generate_mask
+    sc = pg_scene
+    fake = FakeTR(row["T"], sc["obj"], sc["ref_dir"], row["sharp"], row["mid"])
+    ev = FakeEvaluator(fake, oracle, speculate)
+    args = parsearguments.getarguments(["--coarse_mode", row["coarse_mode"]])
+    np.random.seed(42); torch.manual_seed(42); random.seed(42)
+    attacked, qc, best_mask, nbits, best_tr = pg_generate_mask.generate_mask(
+        None, sc["vic"], sc["vic"], 3, sc["mask"].clone(), sc["tar"], sc["tar"], 5, None, "score.py", row["heatmap"],
+        1 - row["tr_hi"], 1 - row["tr_lo"], num_xforms=row["T"], net_size=32, model_type='CIFAR', patch_size=4,
+        max_mask_size=row["max_mask_size"], _evaluator=ev, _args=args)
+    assert int(qc) == row["query_count"]
+    assert float(nbits) == row["nbits"] and float(best_tr) == row["best_tr"]
+    assert best_mask.numpy()[0].astype(np.uint8).tolist() == row["best_mask"]
+    assert _digest(attacked) == row["attacked_sha"]
+    # the baseline pg parameter table was drawn (same np.random consumption as the reference's driver)
+    assert float(np.random.uniform()) == row["np_random_next"] and random.random() == row["py_random_next"]
+    if speculate:
+        assert ev.launches < row["fake_calls"] / 3 and ev.evaluated >= row["fake_calls"]
+    else:
+        assert ev.evaluated == row["fake_calls"]
+
+
+@pytest.mark.parametrize("speculate", [True, False], ids=["fused", "sequential"])
+@pytest.mark.parametrize("row", [r for r in PG_ROWS if r["kind"] == "boost"], ids=lambda r: r["name"])
+def test_pg_boost_matches_reference_driver(row, pg_scene, oracle, speculate):
+    from graphite_amd.patchguard import pg_boost
+    sc = pg_scene
+    fake = FakeTR(row["T"], sc["obj"], sc["ref_dir"], 6.0, 0.1)
+    ev = FakeEvaluator(fake, oracle, speculate)
+    small_mask = torch.zeros(3, 32, 32)
+    small_mask[:, 8:24, 6:26] = 1
+    np.random.seed(42); torch.manual_seed(42)
+    out = pg_boost.boost(None, sc["vic"], 3, small_mask, sc["tar"], 5, beta=1, iterations=row["iterations"], pt_file=None,
+                         num_xforms=row["T"], net_size=32, model_type='CIFAR', bt=row["bt"],
+                         budget_factor=row["budget_factor"], _evaluator=ev)
+    assert len(out) == 5                                   # pg_boost.py:215-216: no best_theta in the CIFAR tuple
+    adv, tr, perturb, queries, adv_small = out
+    assert float(tr) == row["tr"] and int(queries) == row["queries"]
+    assert _digest(adv) == row["adv_sha"] and _digest(perturb) == row["perturb_sha"]
+    assert _digest(adv_small) == row["adv_small_sha"]
+    assert float(torch.rand(1)) == row["torch_random_next"] and float(np.random.uniform()) == row["np_random_next"]
+    assert ev.evaluated == row["fake_calls"] and ev.launches < row["fake_calls"]
+
+
+def test_pg_transforms_interface():
+    """pg_transforms.py's names, defaults and parameter table (the table itself is pinned by test_host_golden)."""
+    import inspect
+    from graphite_amd.patchguard import pg_transforms as P, patchguard_predict
+    assert list(inspect.signature(P.get_transform_params).parameters) == ["num_xforms", "model_type", "nps", "baseline"]
+    assert inspect.signature(P.get_transform_params).parameters["model_type"].default == 'CIFAR'
+    assert list(inspect.signature(P.get_transformed_images).parameters) == ["image", "mask", "transforms", "lbd", "theta",
+                                                                           "pt_file", "net_size"]
+    assert list(inspect.signature(P.convert2Network).parameters) == ["img", "is_torch", "net_size"]
+    np.random.seed(3)
+    a = P.get_transform_params(5, baseline=True)
+    np.random.seed(3)
+    from graphite_amd import transforms as T
+    assert a == T.get_transform_params(5, 'CIFAR', baseline=True, patchguard=True) == [tuple(t) for t in a]
+    assert all(t[1] == 3.0 and t[2] == 1.0 and t[3] in (0, 3) and abs(t[0]) <= 10 for t in a)
+    with pytest.raises(AssertionError):
+        P.get_transform_params(1, model_type='GTSRB')
+    assert patchguard_predict.WINDOW_SIZE == 6
+    with pytest.raises(RuntimeError, match="BagNet"):
+        patchguard_predict.PatchGuard()

@@ -43,3 +43,36 @@ def test_attack_trajectory_matches_oracle():
     assert torch.equal(gpu["theta"], cpu["theta"])
     assert torch.equal(gpu["adversarial"], cpu["adversarial"])
     assert torch.equal(gpu["perturb"], cpu["perturb"])
+
+
+def test_patchguard_attack_trajectory_matches_oracle(tmp_path):
+    """The PatchGuard flavour end to end (patchguard/main_patchguard.py: 32x32 frames, baseline pg parameter table with
+    blur kernels 0 / 3, input normalised to [-0.5, 0.5], no outline file), GPU against the oracle evaluator.  The
+    PatchGuard classifier itself is not available; GTSRBNet (same input convention) stands in behind .predict()."""
+    from graphite_amd.imageio import load_image_u8_hwc, resize_u8_linear, save_image_chw
+    from graphite_amd.patchguard import main_patchguard
+    paths = {}
+    for k in (14, 27):
+        u8 = resize_u8_linear(load_image_u8_hwc(os.path.join(INP, f"GTSRB/images/{k}.png")), 32, 32)
+        paths[k] = str(tmp_path / f"{k}.png")
+        save_image_chw(paths[k], torch.from_numpy(u8.transpose(2, 0, 1).astype(np.float32) / 255.0))
+    sd = synth.gtsrb_state_dict(readout="toy3")
+    T = 20
+
+    def run(evaluator):
+        args = parsearguments.getarguments(["--tr_lo", "0.65", "--tr_hi", "0.85"])
+        model = models.GTSRBNet()
+        model.load_state_dict(sd)
+        np.random.seed(42); torch.manual_seed(42); random.seed(42)
+        return main_patchguard.attack_network(
+            model, paths[14], paths[27], os.path.join(INP, "cifar/masks/mask.png"), 14, 27, None, "score.py", "Target",
+            args.coarse_error, args.reduce_error, 1, T, T, args=args, write_outputs=False, _evaluator=evaluator)
+
+    gpu = run(None)
+    cpu = run(OracleEvaluator.factory(sd))
+    print("pg attack: pixels", gpu["pixels"], "tr", gpu["transform_robustness"], "queries", gpu["queries"])
+    assert gpu["queries"] == cpu["queries"] and gpu["pixels"] == cpu["pixels"]
+    assert gpu["transform_robustness"] == cpu["transform_robustness"]
+    assert torch.equal(gpu["mask"], cpu["mask"]) and torch.equal(gpu["adversarial"], cpu["adversarial"])
+    assert torch.equal(gpu["perturb"], cpu["perturb"])
+    assert gpu["queries"] > 1000
