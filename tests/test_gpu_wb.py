@@ -323,3 +323,46 @@ def test_whitebox_attack_cifar_wideresnet_runs():
     assert r["queries"] > 0 and r["queries"] % 20 == 0
     if r["rounds"] >= 1:                                                      # the attack reached min_tr on the untrained net
         assert r["transform_robustness"] >= 0.5 and r["mask_size"] < 1024
+
+
+def test_whitebox_patch_attack_contract():
+    """The square-patch whitebox attack (reference whitebox/whitebox_patch.py) on the GPU with the 3-sign classifier.
+    No reference run exists to pin its trajectory (kornia / cv2 / the checkpoint are absent): the test checks the script's
+    contract -- positions in its order, only patch pixels change, the reported TR is the best iterate's and is what
+    eval() gives for the returned image, the best position wins, query accounting -- and, independently, recomputes one
+    step by hand from engine.eot_gradient."""
+    import random
+    from cases import INP
+    from graphite_amd import engine
+    from graphite_amd.imageio import load_image_chw
+    from graphite_amd.whitebox_attack import wb_transform_robustness
+    from graphite_amd.whitebox_patch import patch_positions, whitebox_patch_attack
+    assert patch_positions(244, 60) == [(0, 0), (184, 0), (0, 184), (184, 184), (92, 92)]          # :133-134
+    assert patch_positions(32, 9, whole_attack_32=True) == [(0, 0), (23, 0), (0, 23), (23, 23), (12, 12)]   # round(4.5) = 4
+    assert patch_positions(244, 200, limited_loc=False) == [(i, i) for i in range(0, 44, 8)]
+    m, _ = _toy_model()
+    img = torch.from_numpy(load_image_chw(os.path.join(INP, "GTSRB/images/14.png")))
+    np.random.seed(42); torch.manual_seed(42); random.seed(42)
+    xforms = T.get_transform_params(12, 'GTSRB')
+    tab = T.build_wb_table(xforms, 244, 244, PT14)
+    r = whitebox_patch_attack(m, img, 27, PT14, 80, step_size=8 / 255, iters=6, xforms=xforms)
+    assert len(r["per_position"]) == 5 and r["queries"] == 5 * 6 * 2 * 12
+    assert r["transform_robustness"] == max(p["transform_robustness"] for p in r["per_position"])
+    first_best = [p for p in r["per_position"] if p["transform_robustness"] == r["transform_robustness"]][0]
+    assert r["position"] == first_best["position"]                         # strict '>' keeps the first of equal positions
+    i, j = r["position"]
+    adv, mask = r["adversarial"].cpu(), r["mask"].cpu()
+    assert float(mask.sum()) == 3 * 80 * 80 and float(mask[:, i:i + 80, j:j + 80].min()) == 1
+    assert torch.equal(adv[mask < 0.5], img[mask < 0.5])                    # nothing outside the patch moves
+    assert float((adv - img).abs().max()) <= 6 * 8 / 255 + 1e-6 and float(adv.min()) >= 0 and float(adv.max()) <= 1
+    assert wb_transform_robustness(m, img, adv, mask, tab, 27) == r["transform_robustness"]
+    # one step by hand at the first position
+    mask0 = torch.zeros(3, 244, 244); mask0[:, 0:80, 0:80] = 1
+    g, _ = engine.eot_gradient(m, img, img, mask0, tab, 27)
+    step1 = torch.clamp(img - mask0 * (8 / 255) * torch.sign(torch.nan_to_num(g.cpu(), nan=0.0)), 0, 1)
+    r1 = whitebox_patch_attack(m, img, 27, PT14, 80, step_size=8 / 255, iters=1, xforms=xforms)
+    assert r1["per_position"][0]["transform_robustness"] == wb_transform_robustness(m, img, step1, mask0, tab, 27)
+    # the 32 x 32 variant (--whole_attack_32 Y)
+    small = torch.from_numpy(T._chw(torch.nn.functional.interpolate(img[None], size=32, mode="area")[0]))
+    r32 = whitebox_patch_attack(m, small, 27, None, 12, step_size=8 / 255, iters=3, xforms=xforms[:6], whole_attack_32=True)
+    assert len(r32["per_position"]) == 5 and r32["adversarial"].shape == (3, 32, 32) and r32["queries"] == 5 * 3 * 2 * 6
