@@ -12,8 +12,10 @@
 //      pipe only waits at tile boundaries, where the CU's other resident workgroups cover.
 //   * Epilogue as conv_igemm.h: + bias, ReLU, optional 2x2 max-pool in registers (pool windows are
 //     mapped to 4 consecutive accumulator registers), NHWC store.
-// conv2_1 (Cin = 3 padded to 4) uses KW = 1 / CIN = 20: one "tap" is a whole kernel row, whose
-// 5 pixels x 4 channels are contiguous in the tile (PS = 4).
+// conv2_1 (Cin = 3, NHWC4 in HBM) uses KW = 1: one "tap" is a whole kernel row.  PS = 3 / CIN = 16: the tile keeps
+// the three real channels only, so a kernel row's 5 pixels x 3 channels are 15 contiguous floats, + 1 zero-weight k
+// (K = 80; a stride of 3 floats is conflict-free for 32 consecutive pixels).  PS = 4 / CIN = 20: the pad channel
+// is kept (K = 100), the earlier form.
 #pragma once
 #include <hip/hip_runtime.h>
 #include "conv_igemm.h"
@@ -52,6 +54,7 @@ __global__ __launch_bounds__(WM* WN * 64) void k_conv_halo(HaloParams p) {
     static_assert(NP == WN * TN * 32, "n tiling");
     static_assert(KK_TAP % KU == 0, "KU");
     static_assert(CPH % 4 == 0, "CPH");
+    static_assert(PS != 3 || (CPH == 4 && KW == 1 && CIN == 16 && KH * 3 == 15), "packed three-channel rows: conv2_1 only");
 
     extern __shared__ float smem[];
 
@@ -104,11 +107,14 @@ __global__ __launch_bounds__(WM* WN * 64) void k_conv_halo(HaloParams p) {
             for (int u = 0; u < UB; u++) {
                 if (dst[u] >= 0) {
                     float* d = smem + dst[u];
-                    d[0] = v[u].x; d[1] = v[u].y; d[2] = v[u].z; d[3] = v[u].w;
+                    d[0] = v[u].x; d[1] = v[u].y; d[2] = v[u].z;
+                    if (PS != 3) d[3] = v[u].w;          // PS == 3: the pad channel of an NHWC4 pixel is not kept
                 }
             }
         }
     }
+
+    if (PS == 3 && tid == 0) smem[NIMG * IMGS] = 0.f;   // the 16th k of the last pixel's kernel row reads one float past the tile (x 0 weight)
 
     // ---- per-lane A offsets: which pixel of the tile each of my TM m-tiles' row `lp` is ----
     int a_off[TM];

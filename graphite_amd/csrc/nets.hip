@@ -21,6 +21,7 @@
 // ---------------------------------------------------------------------------------------------
 struct Layer {
     float* w = nullptr;      // [K][NP]
+    float* w3 = nullptr;     // conv2_1 only: [k = ky*16 + kx*3 + ci][NP], row ky*16 + 15 zero (conv_halo.h, PS = 3)
     float* bias = nullptr;   // [NP]
     int Cin = 0, Cout = 0, NP = 0, KH = 1, KW = 1, stride = 1, pad = 0;
     int CinT = 0;            // true (unpadded) input channels, for the algorithmic flop count
@@ -98,6 +99,19 @@ static int make_layer(gr_model* m, Layer* L, const float* w, const float* bias, 
     }
     L->CinT = Ci; L->Cin = CinP; L->Cout = Co; L->NP = NP; L->KH = KH; L->KW = KW; L->stride = stride; L->pad = pad;
     return GR_OK;
+}
+
+// conv2_1 for conv_halo.h's packed three-channel rows: k = ky*16 + kx*3 + ci, k = ky*16 + 15 is a zero row.  The
+// accumulation chain visits the real (ky, kx, ci) in the same ascending order as the oracle; the zero-weight steps in
+// between leave the accumulator unchanged (fmaf(a, 0, acc) == acc for finite a), so the logits stay bit-identical.
+static int make_conv21_rows3(gr_model* m, Layer* L, const float* w /* [Co][3][5][5] */, int Co) {
+    const int NP = L->NP;
+    std::vector<float> p((size_t)(5 * 16 + 64) * NP, 0.f);
+    for (int o = 0; o < Co; o++)
+        for (int i = 0; i < 3; i++)
+            for (int y = 0; y < 5; y++)
+                for (int x = 0; x < 5; x++) p[(size_t)(y * 16 + x * 3 + i) * NP + o] = w[(((size_t)o * 3 + i) * 5 + y) * 5 + x];
+    return upload(m, p, &L->w3);
 }
 
 // float -> bfloat16, round to nearest even (what v_cvt_pk_bf16_f32 does; no NaNs in weights)
@@ -229,6 +243,7 @@ extern "C" int gr_model_load_gtsrb(gr_ctx* ctx, const float* const* t, const int
         rc = upload(m, c, &m->c11);
     }
     for (int l = 1; l <= 6 && !rc; l++) rc = make_layer(m, &m->g[l - 1], t[2 * l], t[2 * l + 1], co[l], ci[l], 5, 5, 1, 2);
+    if (!rc) rc = make_conv21_rows3(m, &m->g[0], t[2], co[1]);
     if (!rc) rc = make_conv21_bf16(m, &m->g[0], t[2]);
     for (int l = 2; l <= 6 && !rc; l++) rc = make_layer_bf16(m, &m->g[l - 1], t[2 * l], co[l], ci[l]);   // conv2_2 .. conv4_2
     if (!rc) {
@@ -644,9 +659,13 @@ static int run_gtsrb_halo(gr_ctx* ctx, const Layer& L, int layer, const float* i
     switch (layer * 8 + v) {            // variant 0 of each layer = the fastest measured (profiles/r01_tune_*.log)
     case 2 * 8 + 7: HL( 32, 32, 5, 5,  33,  8, 16, 1,  4, 2, 1, 1,  8,  64, false, 0); break;   // conv3_1, small launch
     case 4 * 8 + 7: HL( 64, 64, 5, 5,  65,  8,  8, 1,  2, 4, 1, 1, 16, 128, false, 0); break;   // conv4_1, small launch
-    case 0 * 8 + 0: HL( 20,  4, 5, 1,   4, 16, 32, 1,  4, 1, 4, 1,  5,  32, false, 1); break;   // conv2_1
-    case 0 * 8 + 1: HL( 20,  4, 5, 1,   4, 16, 32, 1,  4, 1, 4, 1,  5,  32, false, 0); break;
-    case 0 * 8 + 2: HL( 20,  4, 5, 1,   4,  8, 32, 1,  4, 1, 2, 1,  5,  32, false, 0); break;
+    case 0 * 8 + 0: p.wgt = L.w3; HL( 16,  4, 5, 1,   3, 16, 32, 1,  4, 1, 4, 1,  8,  32, false, 1); break;   // conv2_1, K = 80
+    case 0 * 8 + 1: p.wgt = L.w3; HL( 16,  4, 5, 1,   3, 16, 32, 1,  4, 1, 4, 1,  4,  32, false, 1); break;
+    case 0 * 8 + 2: p.wgt = L.w3; HL( 16,  4, 5, 1,   3, 16, 32, 1,  4, 1, 4, 1,  8,  32, false, 0); break;
+    case 0 * 8 + 3: p.wgt = L.w3; HL( 16,  4, 5, 1,   3,  8, 32, 1,  4, 1, 2, 1,  8,  32, false, 0); break;
+    case 0 * 8 + 4: HL( 20,  4, 5, 1,   4, 16, 32, 1,  4, 1, 4, 1,  5,  32, false, 1); break;   // conv2_1 with the pad channel, K = 100
+    case 0 * 8 + 5: HL( 20,  4, 5, 1,   4, 16, 32, 1,  4, 1, 4, 1,  5,  32, false, 0); break;
+    case 0 * 8 + 6: HL( 20,  4, 5, 1,   4,  8, 32, 1,  4, 1, 2, 1,  5,  32, false, 0); break;
     case 1 * 8 + 0: HL( 32, 32, 5, 5,  33,  8, 32, 1,  4, 1, 2, 1, 16,  32, true , 0); break;   // conv2_2
     case 1 * 8 + 1: HL( 32, 32, 5, 5,  33,  8, 32, 1,  4, 1, 2, 1,  8,  32, true , 0); break;
     case 1 * 8 + 2: HL( 32, 32, 5, 5,  33, 16, 32, 1,  4, 1, 4, 1,  8,  32, true , 0); break;
