@@ -6,12 +6,12 @@
 
 static thread_local std::string g_create_err;
 
-// Scratch of gr_transform_composited_static (the entry point that allocates nothing): the RGBX composites of ONE
+// Scratch of gr_transform_composited_static (the entry point that allocates nothing): the RGB composites (12-byte texels) of ONE
 // (img, mask_lg, pert) triple, one per blur kernel in use (<= 4), for frames of at most GR_STATIC_MAX_PIXELS pixels.
 // Every GPU the library runs on holds its own copy until the process ends.  In host code the NAME is only a handle for
 // hipGetSymbolAddress (gr_ctx_create resolves it once per device, with that device current); kernels, memsets and copies
 // take the resolved per-device pointer gr_ctx::static_scratch.
-static __device__ __align__(256) unsigned char scratch[(size_t)4 * GR_STATIC_MAX_PIXELS * 16];
+static __device__ __align__(256) unsigned char scratch[(size_t)4 * GR_STATIC_MAX_PIXELS * ATT_B];
 
 int gr_fail(gr_ctx* ctx, int code, const char* fmt, ...) {
     char buf[512];
@@ -312,7 +312,7 @@ extern "C" int gr_transform_composited(gr_ctx* ctx, const float* img, const floa
     int rc = check_frame(ctx, H, W, H, W, net, xf);
     if (rc) return rc;
     hipStream_t st = (hipStream_t)stream;
-    size_t att_bytes = gr_align((size_t)xf->nslots * H * W * 16);
+    size_t att_bytes = gr_align((size_t)xf->nslots * H * W * ATT_B);
     if ((rc = gr_ws_reserve(ctx, att_bytes, stream))) return rc;
     float* att = (float*)ctx->ws;
     if ((rc = px_composite_from_pert(ctx, img, mask_lg, pert, H, W, xf, att, st))) return rc;
@@ -346,7 +346,7 @@ extern "C" int gr_transform_composited_var(gr_ctx* ctx, const float* img, const 
     if (net_size == 32) return gr_fail(ctx, GR_EINVAL, "net_size 32 is the fixed-size branch: use gr_transform_composited");
     if (out_stride < var_image_floats(xf, net_size)) return gr_fail(ctx, GR_EINVAL, "gr_transform_composited_var: out_stride too small");
     hipStream_t st = (hipStream_t)stream;
-    size_t att_bytes = gr_align((size_t)xf->nslots * H * W * 16);
+    size_t att_bytes = gr_align((size_t)xf->nslots * H * W * ATT_B);
     if ((rc = gr_ws_reserve(ctx, att_bytes, stream))) return rc;
     float* att = (float*)ctx->ws;
     if ((rc = px_composite_from_pert(ctx, img, mask_lg, pert, H, W, xf, att, st))) return rc;
@@ -364,7 +364,7 @@ extern "C" int gr_warp_batch_var(gr_ctx* ctx, const float* img, int H, int W, co
     if (net_size == 32) return gr_fail(ctx, GR_EINVAL, "net_size 32 is the fixed-size branch: use gr_warp_batch");
     if (out_stride < var_image_floats(xf, net_size)) return gr_fail(ctx, GR_EINVAL, "gr_warp_batch_var: out_stride too small");
     hipStream_t st = (hipStream_t)stream;
-    const size_t per_cand = (size_t)xf->nslots * H * W * 16;
+    const size_t per_cand = (size_t)xf->nslots * H * W * ATT_B;
     int cpass = (int)(((size_t)2 << 30) / per_cand);
     if (cpass < 1) cpass = 1;
     if (cpass > C) cpass = C;
@@ -411,7 +411,7 @@ extern "C" int gr_warp_batch(gr_ctx* ctx, const float* img, int H, int W, const 
     int rc = check_frame(ctx, H, W, nh, nw, net, xf);
     if (rc) return rc;
     hipStream_t st = (hipStream_t)stream;
-    const size_t per_cand = (size_t)xf->nslots * H * W * 16;
+    const size_t per_cand = (size_t)xf->nslots * H * W * ATT_B;
     // candidates per pass bounded by ~2 GiB of composites
     int cpass = (int)(((size_t)2 << 30) / per_cand);
     if (cpass < 1) cpass = 1;
@@ -517,7 +517,7 @@ extern "C" int gr_tr_hits(gr_ctx* ctx, gr_model* m, const float* img, int H, int
     // the classifier's NHWC4 input (GTSRBNet: after conv1_1 + ReLU) straight into the net scratch: no CHW image buffer,
     // no layout-change kernel in between.
     const int max_cand = (int)((chunk + T - 1) / T + 1);
-    const size_t per_cand = (size_t)xf->nslots * H * W * 16;
+    const size_t per_cand = (size_t)xf->nslots * H * W * ATT_B;
     const size_t att_bytes = gr_align(per_cand * (size_t)(max_cand < C ? max_cand : C));
     const size_t lg_bytes = gr_align((size_t)chunk * ncls * sizeof(float));
     const size_t net_bytes = net_workspace_bytes(m, chunk);

@@ -75,6 +75,11 @@ int gr_ws_reserve(gr_ctx* ctx, size_t bytes, void* stream);
 
 static inline size_t gr_align(size_t v, size_t a = 256) { return (v + a - 1) / a * a; }
 
+// Composite texels: the three channels of a pixel packed as 12 bytes (a texel is what one gather of the warp kernels
+// fetches; without a pad float a sampled source row drags a quarter fewer cache lines through L1).
+constexpr int ATT_C = 3;                     // floats per composite texel
+constexpr int ATT_B = ATT_C * 4;             // bytes per composite texel
+
 // ---- pixel.hip (launchers used by api.hip) ----
 int px_resize(gr_ctx*, const float* src, int C, int sh, int sw, float* dst, int dh, int dw, int clamp, int normalize,
               hipStream_t);
@@ -82,7 +87,7 @@ int px_add_noise(gr_ctx*, const float* img, int H, int W, const float* mask, con
                  float lbd, int clip, float* comb, float* pert, float* mask_lg, hipStream_t);
 int px_warp_full(gr_ctx*, const float* src, int H, int W, const double* Mi, int crop_x, int crop_y, float* dst,
                  hipStream_t);
-// composites for `ncand` candidates: att = [ncand][nslots][H][W][4] f32 (RGBX)
+// composites for `ncand` candidates: att = [ncand][nslots][H][W][3] f32 (RGB, ATT_B bytes per texel)
 int px_composite(gr_ctx*, const float* img, int H, int W, const float* masks, const float* thetas, int ncand, int nh,
                  int nw, float lbd, const gr_xforms* xf, float* att, hipStream_t);
 int px_composite_from_pert(gr_ctx*, const float* img, const float* mask_lg, const float* pert, int H, int W,

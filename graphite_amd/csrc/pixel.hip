@@ -1,7 +1,7 @@
 // pixel.hip -- the image half of the transform-robustness path, hand-written for gfx950.
 //
 //   k_composite   add_noise (transforms.py:143-159) + GaussianBlur/where/clip (transforms.py:55-62)
-//                 fused per 32x32 tile; one RGBX f32 composite per (candidate, blur kernel).
+//                 fused per 32x32 tile; one RGB f32 composite (12-byte texels) per (candidate, blur kernel).
 //   k_warp_net    warpPerspective (perspective_transform.py:47) + gamma LUT (transforms.py:69-75)
 //                 + resize to net x net + clamp + normalise (transforms.py:18-29), fused, and
 //                 evaluated ON DEMAND: the resize reads a 2x2 neighbourhood of the warp per output
@@ -185,7 +185,7 @@ __global__ __launch_bounds__(256) void k_composite(const float* __restrict__ img
             }
             __syncthreads();
         }
-        float* dst = att + ((size_t)cand * nslots + s) * pl * 4;
+        float* dst = att + ((size_t)cand * nslots + s) * pl * ATT_C;
         for (int j = 0; j < 4; j++) {
             int y = tid / CT + 8 * j, x = tid % CT;
             int gy = ty0 + y, gx = tx0 + x;
@@ -196,7 +196,7 @@ __global__ __launch_bounds__(256) void k_composite(const float* __restrict__ img
                     float base = img[c * pl + (size_t)gy * W + gx];
                     o[c] = clamp01(s_msk[c][y + CHALO][x + CHALO] ? v : base);
                 }
-                *reinterpret_cast<float4*>(dst + ((size_t)gy * W + gx) * 4) = make_float4(o[0], o[1], o[2], 0.f);
+                *reinterpret_cast<float3*>(dst + ((size_t)gy * W + gx) * ATT_C) = make_float3(o[0], o[1], o[2]);
             }
         }
         __syncthreads();
@@ -247,11 +247,11 @@ __device__ __forceinline__ float gamma_stage_f(float v, const float* lutf) {
     return lutf[((int)s) & 255];
 }
 
-// warped + gamma'd pixel from an RGBX composite
-__device__ __forceinline__ void warp_gamma_rgbx(const float4* __restrict__ att, const double* Mi, int bw0, int x, int y,
+// warped + gamma'd pixel from an RGB composite (12-byte texels)
+__device__ __forceinline__ void warp_gamma_rgbx(const float3* __restrict__ att, const double* Mi, int bw0, int x, int y,
                                                 int H, int W, const float* lutf, float* o3) {
     WarpTaps t = warp_taps(Mi, bw0, x, y, H, W);
-    float4 a = att[t.o00], b = att[t.o01], c = att[t.o10], d = att[t.o11];
+    float3 a = att[t.o00], b = att[t.o01], c = att[t.o10], d = att[t.o11];
     o3[0] = gamma_stage_f(a.x * t.w0 + b.x * t.w1 + c.x * t.w2 + d.x * t.w3, lutf);
     o3[1] = gamma_stage_f(a.y * t.w0 + b.y * t.w1 + c.y * t.w2 + d.y * t.w3, lutf);
     o3[2] = gamma_stage_f(a.z * t.w0 + b.z * t.w1 + c.z * t.w2 + d.z * t.w3, lutf);
@@ -297,7 +297,7 @@ __global__ __launch_bounds__(256) void k_warp_net_any(const float* __restrict__ 
     __syncthreads();
     const int cw = s_par[0], ch = s_par[1], bw0 = s_par[3];
     const size_t pl = (size_t)H * W;
-    const float4* att = reinterpret_cast<const float4*>(att_all) + ((size_t)cand * nslots + s_par[2]) * pl;
+    const float3* att = reinterpret_cast<const float3*>(att_all) + ((size_t)cand * nslots + s_par[2]) * pl;
     int nx = net, ny = net;
     if (var) { net_size_rule(cw, ch, net, &nx, &ny); normalize = 0; }
     const double scx = 1.0 / ((double)nx / (double)cw), scy = 1.0 / ((double)ny / (double)ch);
@@ -404,7 +404,7 @@ __global__ __launch_bounds__(256) void k_warp_net32(const float* __restrict__ at
     }
     __syncthreads();
     const size_t pl = (size_t)H * W;
-    const float4* att = reinterpret_cast<const float4*>(att_all) + ((size_t)cand * nslots + x->slot) * pl;
+    const float3* att = reinterpret_cast<const float3*>(att_all) + ((size_t)cand * nslots + x->slot) * pl;
     const double m4 = s_Mi[4], m5 = s_Mi[5];
 #pragma unroll 1
     for (int p = tid; p < net * net; p += 256) {
@@ -418,7 +418,7 @@ __global__ __launch_bounds__(256) void k_warp_net32(const float* __restrict__ at
             const double my[2] = {m4 * ty.i0, m4 * ty.i1};
 #pragma unroll
             for (int jy = 0; jy < 2; jy++) {
-                float4 tp[2][4];
+                float3 tp[2][4];
                 float w[2][4];
 #pragma unroll
                 for (int jx = 0; jx < 2; jx++) {
@@ -575,13 +575,13 @@ __global__ __launch_bounds__(256) void k_warp_quad(const float* __restrict__ att
     }
     __syncthreads();
     const size_t pl = (size_t)H * W;
-    const char* att = reinterpret_cast<const char*>(att_all) + ((size_t)cand * nslots + x->slot) * pl * 16;
-    const unsigned Wb = (unsigned)W * 16u;        // 32-bit byte offsets from a uniform base (the launcher checks the frame size)
+    const char* att = reinterpret_cast<const char*>(att_all) + ((size_t)cand * nslots + x->slot) * pl * ATT_B;
+    const unsigned Wb = (unsigned)W * (unsigned)ATT_B;   // 32-bit byte offsets from a uniform base (the launcher checks the frame size)
     const int lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int hh = lane & 1, jx = (lane >> 1) & 1;
     const int ox = (wv & 1) * 16 + (lane >> 2);
     const int k = 2 * ox + jx;
-    const unsigned sxb = 16u * (unsigned)(hh ? s_col[k].sx1 : s_col[k].sx0);
+    const unsigned sxb = (unsigned)ATT_B * (unsigned)(hh ? s_col[k].sx1 : s_col[k].sx0);
     const float fx = s_col[k].fx;
     const float wx = hh ? fx : 1.f - fx;
     const Tap tx = s_tx[ox];
@@ -590,7 +590,7 @@ __global__ __launch_bounds__(256) void k_warp_quad(const float* __restrict__ att
         const int oy = (wv >> 1) + 2 * i;
         const Tap ty = s_ty[oy];
         float g[2][3];
-        float4 tt[2], tb[2];
+        float3 tt[2], tb[2];
         float wt[2], wb[2];
 #pragma unroll
         for (int jy = 0; jy < 2; jy++) {
@@ -600,8 +600,8 @@ __global__ __launch_bounds__(256) void k_warp_quad(const float* __restrict__ att
             const float fy = (float)((e >> 16) & 31) * (1.f / 32.f);
             wt[jy] = (1.f - fy) * wx;             // w0 (even lane) / w1 (odd lane)
             wb[jy] = fy * wx;                     // w2 / w3
-            tt[jy] = *reinterpret_cast<const float4*>(att + ot);
-            tb[jy] = *reinterpret_cast<const float4*>(att + ob);
+            tt[jy] = *reinterpret_cast<const float3*>(att + ot);
+            tb[jy] = *reinterpret_cast<const float3*>(att + ob);
         }
 #pragma unroll
         for (int jy = 0; jy < 2; jy++) {
@@ -721,7 +721,7 @@ __global__ __launch_bounds__(WB_NT) void k_warp_band(const float* __restrict__ a
     const int cand = cand_lo + cl;
     const int tid = threadIdx.x;
     const size_t pl = (size_t)H * W;
-    const float4* att = reinterpret_cast<const float4*>(att_all) + ((size_t)(cand - cand0) * nslots + g.slot) * pl;
+    const float3* att = reinterpret_cast<const float3*>(att_all) + ((size_t)(cand - cand0) * nslots + g.slot) * pl;
 
     // ---- per-image tables ----
     {
@@ -797,7 +797,10 @@ __global__ __launch_bounds__(WB_NT) void k_warp_band(const float* __restrict__ a
             const int i = tid + u * WB_NT;
             const int row = i / BW, col = i - row * BW;
             pre[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (i < npx && c0 + col < W) pre[u] = att[(size_t)row * W + c0 + col];
+            if (i < npx && c0 + col < W) {            // 12-byte texel in HBM, 16-byte slot in LDS
+                const float3 t3 = att[(size_t)row * W + c0 + col];
+                pre[u] = make_float4(t3.x, t3.y, t3.z, 0.f);
+            }
         }
     };
     auto stash = [&]() {
@@ -866,8 +869,10 @@ __global__ __launch_bounds__(WB_NT) void k_warp_band(const float* __restrict__ a
                         tp[jx][0] = band[r0[jx] * BW + q0]; tp[jx][1] = band[r0[jx] * BW + q1];
                         tp[jx][2] = band[r1[jx] * BW + q0]; tp[jx][3] = band[r1[jx] * BW + q1];
                     } else {
-                        tp[jx][0] = att[(size_t)r0[jx] * W + sx0[jx]]; tp[jx][1] = att[(size_t)r0[jx] * W + sx1[jx]];
-                        tp[jx][2] = att[(size_t)r1[jx] * W + sx0[jx]]; tp[jx][3] = att[(size_t)r1[jx] * W + sx1[jx]];
+                        const float3 g0 = att[(size_t)r0[jx] * W + sx0[jx]], g1 = att[(size_t)r0[jx] * W + sx1[jx]];
+                        const float3 g2 = att[(size_t)r1[jx] * W + sx0[jx]], g3 = att[(size_t)r1[jx] * W + sx1[jx]];
+                        tp[jx][0] = make_float4(g0.x, g0.y, g0.z, 0.f); tp[jx][1] = make_float4(g1.x, g1.y, g1.z, 0.f);
+                        tp[jx][2] = make_float4(g2.x, g2.y, g2.z, 0.f); tp[jx][3] = make_float4(g3.x, g3.y, g3.z, 0.f);
                     }
                 }
 #pragma unroll
@@ -984,15 +989,15 @@ int px_composite(gr_ctx* ctx, const float* img, int H, int W, const float* masks
                  int nh, int nw, float lbd, const gr_xforms* xf, float* att, hipStream_t st) {
     if (ncand <= 0) return GR_OK;
     int tiles = ((W + CT - 1) / CT) * ((H + CT - 1) / CT);
-    // algorithmic bytes: image once + (mask, theta) per candidate + one RGBX composite per (candidate, blur)
+    // algorithmic bytes: image once + (mask, theta) per candidate + one RGB composite per (candidate, blur)
     ProfScope ps_(ctx, "k_composite", st, 0.0,
-                  12.0 * H * W + (double)ncand * (24.0 * nh * nw + 16.0 * xf->nslots * H * W));
+                  12.0 * H * W + (double)ncand * (24.0 * nh * nw + (double)ATT_B * xf->nslots * H * W));
     for (int c0 = 0; c0 < ncand; c0 += 32768) {        // gridDim.y limit
         int nc = ncand - c0 < 32768 ? ncand - c0 : 32768;
         hipLaunchKernelGGL(k_composite<false>, dim3(tiles, nc), dim3(256), 0, st, img, H, W,
                            masks + (size_t)c0 * 3 * nh * nw, thetas + (size_t)c0 * 3 * nh * nw, nh, nw,
                            inv_scale(nw, W), inv_scale(nh, H), lbd, xf->nslots, xf->slot_blur[0], xf->slot_blur[1],
-                           xf->slot_blur[2], xf->slot_blur[3], att + (size_t)c0 * xf->nslots * H * W * 4);
+                           xf->slot_blur[2], xf->slot_blur[3], att + (size_t)c0 * xf->nslots * H * W * ATT_C);
     }
     GR_HIP(ctx, hipGetLastError());
     return GR_OK;
@@ -1075,7 +1080,7 @@ int px_warp_net(gr_ctx* ctx, const float* att, int H, int W, const gr_xforms* xf
         if (quad < 0) { const char* e = getenv("GRAPHITE_WARP_QUAD"); quad = (e && e[0] == '0') ? 0 : 1; }
 #define WN(K, M) hipLaunchKernelGGL(K<M>, dim3(grid), dim3(256), 0, st, att, H, W, xf->nslots, xf->dev, xf->T, \
                                     (long long)n_begin, cand0, normalize, count, use_map, c11, out)
-        if (quad && xf->all_sep && H <= 32768 && W <= (1 << 19) && (long long)H * W * 16 <= 0xffffffffLL) {   // row table packs a source row in 16 bits
+        if (quad && xf->all_sep && H <= 32768 && W <= (1 << 19) && (long long)H * W * ATT_B <= 0xffffffffLL) {   // row table packs a source row in 16 bits
             if (out_mode == GR_OUT_CHW) WN(k_warp_quad, GR_OUT_CHW);
             else if (out_mode == GR_OUT_NHWC4) WN(k_warp_quad, GR_OUT_NHWC4);
             else WN(k_warp_quad, GR_OUT_NHWC4_C11);

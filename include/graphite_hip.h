@@ -122,8 +122,8 @@ int gr_warp_batch_var(gr_ctx* ctx, const float* img, int H, int W, const float* 
                       int nw, const gr_xforms* xf, float lbd, int net_size, float* out, int64_t out_stride, void* stream);
 /* gr_transform_composited for callers that cannot allocate device memory (code under HIP graph capture, tight serving
  * loops, harnesses that forbid hipMalloc).  No counterpart in the reference.  Same arguments, same results bit for bit;
- * the composites (one RGBX f32 image per blur kernel in use, <= 4) are kept in a file-scope __device__ array of
- * 4 * GR_STATIC_MAX_PIXELS * 16 bytes (4 MiB) that every GPU the library runs on holds until the process ends, instead of
+ * the composites (one RGB f32 image, 12-byte texels, per blur kernel in use, <= 4) are kept in a file-scope __device__ array of
+ * 4 * GR_STATIC_MAX_PIXELS * 12 bytes (3 MiB) that every GPU the library runs on holds until the process ends, instead of
  * the growable workspace: the call makes no hipMalloc / hipFree and creates no events.  GR_EINVAL when H*W exceeds
  * GR_STATIC_MAX_PIXELS (244x244 GTSRB frames fit); GR_ESTATE while gr_profile_enable is on.  All calls on one GPU share
  * that array: calls that overlap on one GPU (two streams, two contexts on the same device) race.  Nothing in it has to
