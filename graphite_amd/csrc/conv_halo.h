@@ -27,6 +27,7 @@ struct HaloParams {
     float* out;           // [B,H,W,Cout] or pooled [B,H/2,W/2,Cout]
     int B, H, W, Cout;
     int relu;
+    int dbg;              // tuning aid (GRAPHITE_HALO_DBG): 1 = skip the tile staging, 2 = skip the MFMA loop, 4 = skip the epilogue (wrong results)
 };
 
 // CIN: k extent of one tap; CPH: physical channels per pixel; KH,KW: taps; PS: LDS pixel stride (floats);
@@ -85,6 +86,7 @@ __global__ __launch_bounds__(WM* WN * 64) void k_conv_halo(HaloParams p) {
         constexpr int TOT = NIMG * THH * TWH * SEG;
         constexpr int IT = (TOT + NT - 1) / NT;
         constexpr int UB = 8;
+        if (!(p.dbg & 1))
 #pragma unroll
         for (int it0 = 0; it0 < IT; it0 += UB) {
             float4 v[UB];
@@ -168,6 +170,7 @@ __global__ __launch_bounds__(WM* WN * 64) void k_conv_halo(HaloParams p) {
         if (++nsub == SUBS) { nsub = 0; if (++nkx == KW) { nkx = 0; if (++nky == KH) nky = 0; } }
         return a_tap;
     };
+    if (p.dbg & 2) { __syncthreads(); } else
     if (PIPE == 0) {
         auto load_b = [&](float (&br)[KU][TN]) {
 #pragma unroll
@@ -253,6 +256,7 @@ __global__ __launch_bounds__(WM* WN * 64) void k_conv_halo(HaloParams p) {
     }
 
     // ---- epilogue ----
+    if (p.dbg & 4) return;
     if (!POOL) __syncthreads();                   // the LDS patches below overlay the input tile other waves may still read
     // Row r of an accumulator tile belongs to tile row i_r = (r&3) + 8*(r>>2) + 4*lh, i.e. NOT this lane's
     // own `lp` pixel: recompute the pixel of each row from the m-tile mapping.

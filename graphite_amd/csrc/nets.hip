@@ -640,6 +640,7 @@ static int bf16_variant(int layer) {
 static int run_gtsrb_halo(gr_ctx* ctx, const Layer& L, int layer, const float* in, int B, int H, float* out, hipStream_t st) {
     HaloParams p;
     p.in = in; p.wgt = L.w; p.bias = L.bias; p.out = out; p.B = B; p.H = H; p.W = H; p.Cout = L.Cout; p.relu = 1;
+    { static int dbg = -1; if (dbg < 0) { const char* e = getenv("GRAPHITE_HALO_DBG"); dbg = e ? atoi(e) : 0; } p.dbg = dbg; }
     const bool pool = layer == 1 || layer == 3 || layer == 5;
     const double M = (double)B * H * H;
     const double flops = 2.0 * M * L.Cout * 25 * L.CinT;
