@@ -33,6 +33,49 @@ __global__ __launch_bounds__(256) void k_mfma(const bf16x8* __restrict__ ops, fl
     if (s == 12345.678f) out[blockIdx.x * blockDim.x + threadIdx.x] = s;
 }
 
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+// the same flop count per iteration with v_mfma_f32_16x16x32_bf16 (4 x NACC accumulators of 4 registers)
+template <int NACC>
+__global__ __launch_bounds__(256) void k_mfma16(const bf16x8* __restrict__ ops, float* out, int iters) {
+    f32x4 acc[NACC * 2];
+#pragma unroll
+    for (int i = 0; i < NACC * 2; i++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) acc[i][r] = 0.f;
+    bf16x8 a[4], b[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) { a[u] = ops[(threadIdx.x * 8 + u) & 4095]; b[u] = ops[(threadIdx.x * 8 + 4 + u) & 4095]; }
+    for (int it = 0; it < iters; it++) {
+#pragma unroll
+        for (int u = 0; u < 4; u++)
+#pragma unroll
+            for (int i = 0; i < NACC * 2; i++) acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[u], b[(u + i) & 3], acc[i], 0, 0, 0);
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NACC * 2; i++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) s += acc[i][r];
+    if (s == 12345.678f) out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+
+template <int NACC>
+static void run16(const char* name, int wg_per_cu, int ncu, const bf16x8* ops, float* out, int iters) {
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    dim3 grid(ncu * wg_per_cu), block(256);
+    hipLaunchKernelGGL(k_mfma16<NACC>, grid, block, 0, 0, ops, out, 64);
+    hipDeviceSynchronize();
+    hipEventRecord(e0);
+    hipLaunchKernelGGL(k_mfma16<NACC>, grid, block, 0, 0, ops, out, iters);
+    hipEventRecord(e1);
+    hipEventSynchronize(e1);
+    float ms = 0.f;
+    hipEventElapsedTime(&ms, e0, e1);
+    double flops = (double)grid.x * 4 * iters * 4.0 * NACC * 2 * 16384.0;
+    printf("%-40s grid %5d  %8.3f ms  %7.1f TFLOP/s\n", name, grid.x, ms, flops / ms / 1e9);
+}
+
 template <int NACC>
 static void run(const char* name, int wg_per_cu, int ncu, const bf16x8* ops, float* out, int iters) {
     hipEvent_t e0, e1;
@@ -72,6 +115,8 @@ int main() {
         run<4>("random, 4 acc/wave, 2 waves/SIMD", 2, ncu, rnd, out, 16384);
         run<2>("random, 2 acc/wave, 4 waves/SIMD", 4, ncu, rnd, out, 16384);
         run<4>("zeros,  4 acc/wave, 2 waves/SIMD", 2, ncu, zero, out, 16384);
+        run16<4>("random, 16x16x32, 8 acc/wave, 2 waves/SIMD", 2, ncu, rnd, out, 16384);
+        run16<2>("random, 16x16x32, 4 acc/wave, 4 waves/SIMD", 4, ncu, rnd, out, 16384);
     }
     return 0;
 }
