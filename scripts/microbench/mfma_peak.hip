@@ -12,12 +12,24 @@ __global__ __launch_bounds__(256) void k_mfma(float* out, int iters, float a0, f
     for (int i = 0; i < NACC; i++)
 #pragma unroll
         for (int r = 0; r < 16; r++) acc[i][r] = 0.f;
-    float a = a0 + threadIdx.x * 1e-6f, b = b0;
+    // a0 < 0: RANDOM operand bits (a hash of the lane, values in about [-2, 2)) -- the part lowers its clock under an
+    // MFMA-dense load on non-trivial data; otherwise the near-constant operands of the first version of this benchmark
+    float av[4], bv[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+        if (a0 < 0.f) {
+            unsigned h = (threadIdx.x * 2654435761u) ^ (u * 0x9e3779b9u) ^ (blockIdx.x * 40503u);
+            h ^= h >> 15; h *= 0x2c1b3c6du; h ^= h >> 12;
+            av[u] = __uint_as_float(0x3f000000u | (h & 0x80ffffffu)) ;          // +-[0.5, 2)
+            h *= 0x297a2d39u; h ^= h >> 15;
+            bv[u] = __uint_as_float(0x3f000000u | (h & 0x80ffffffu));
+        } else { av[u] = a0 + threadIdx.x * 1e-6f; bv[u] = b0; }
+    }
     for (int it = 0; it < iters; it++) {
 #pragma unroll
         for (int u = 0; u < 4; u++)
 #pragma unroll
-            for (int i = 0; i < NACC; i++) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[i], 0, 0, 0);
+            for (int i = 0; i < NACC; i++) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u], bv[(u + i) & 3], acc[i], 0, 0, 0);
     }
     float s = 0.f;
 #pragma unroll
@@ -28,15 +40,15 @@ __global__ __launch_bounds__(256) void k_mfma(float* out, int iters, float a0, f
 }
 
 template <int NACC>
-static void run(const char* name, int wg_per_cu, int ncu, float* out) {
+static void run(const char* name, int wg_per_cu, int ncu, float* out, float a0 = 1.0f) {
     const int iters = 4096;
     hipEvent_t e0, e1;
     hipEventCreate(&e0); hipEventCreate(&e1);
     dim3 grid(ncu * wg_per_cu), block(256);
-    hipLaunchKernelGGL(k_mfma<NACC>, grid, block, 0, 0, out, 64, 1.0f, 1e-3f);
+    hipLaunchKernelGGL(k_mfma<NACC>, grid, block, 0, 0, out, 64, a0, 1e-3f);
     hipDeviceSynchronize();
     hipEventRecord(e0);
-    hipLaunchKernelGGL(k_mfma<NACC>, grid, block, 0, 0, out, iters, 1.0f, 1e-3f);
+    hipLaunchKernelGGL(k_mfma<NACC>, grid, block, 0, 0, out, iters, a0, 1e-3f);
     hipEventRecord(e1);
     hipEventSynchronize(e1);
     float ms = 0.f;
@@ -61,6 +73,11 @@ int main() {
     run<1>("1 acc/wave, 4 waves/SIMD", 4, ncu, out);
     // long run: sustained clocks
     for (int rep = 0; rep < 3; rep++) run<10>("10 acc/wave, 2 waves (rep)", 8, ncu, out);
+    for (int rep = 0; rep < 3; rep++) {
+        run<4>("RANDOM, 4 acc/wave, 2 waves/SIMD", 2, ncu, out, -1.f);
+        run<2>("RANDOM, 2 acc/wave, 2 waves/SIMD", 2, ncu, out, -1.f);
+        run<10>("RANDOM, 10 acc/wave, 2 waves (long)", 8, ncu, out, -1.f);
+    }
     hipFree(out);
     return 0;
 }
