@@ -103,3 +103,53 @@ def test_a_wrong_upsample_fails_the_same_fit(oracle, kind):
 def test_hip_upsample_reproduces_reference_attack_png(name, npx):
     from graphite_amd import _hip
     _check(_hip.resize_linear, name, npx)
+
+
+# ---- second reference-held pin: inputs/GTSRB/images/14_300.png -> 14.png (main.py:38,49,59 resize with cv2.resize) ----
+# 14.png (244 x 244) is cv2.resize(14_300.png, (244, 244)) written by real OpenCV: the 8-bit fixed-point INTER_LINEAR
+# restatement in graphite_amd.imageio reproduces it BIT FOR BIT (0 of 178,608 values differ), which pins the tap rule
+# (d + 0.5) * scale - 0.5 in float32, the 11-bit coefficients and the >>4 / >>16 / (+2)>>2 vertical pass against real
+# OpenCV output.  The float32 resize of the oracle / HIP library (transforms.py:23,148,151) shares that tap rule: pushed
+# through the same pair it must land within one 8-bit level (the fixed-point path rounds twice).
+
+def _pair_300():
+    from graphite_amd.imageio import load_image_u8_hwc
+    big = load_image_u8_hwc(os.path.join(INP, "GTSRB/images/14_300.png"))
+    small = load_image_u8_hwc(os.path.join(INP, "GTSRB/images/14.png"))
+    assert big.shape == (300, 300, 3) and small.shape == (244, 244, 3)
+    return big, small
+
+
+def test_resize_u8_linear_reproduces_reference_14_png_exactly():
+    from graphite_amd.imageio import resize_u8_linear
+    big, small = _pair_300()
+    got = resize_u8_linear(big, 244, 244)
+    assert got.dtype == np.uint8 and got.shape == small.shape
+    assert int((got != small).sum()) == 0
+
+
+def test_a_wrong_u8_resize_does_not_reproduce_14_png():
+    """Negative control: Pillow's bilinear (support-scaled, i.e. anti-aliased) is a different operator."""
+    big, small = _pair_300()
+    pil = np.asarray(Image.fromarray(big).resize((244, 244), Image.BILINEAR))
+    assert int((pil != small).sum()) > 1000
+
+
+def _float_resize_levels(resize):
+    big, small = _pair_300()
+    x = np.ascontiguousarray(big.astype(np.float32).transpose(2, 0, 1))          # levels 0..255 in float32
+    out = np.asarray(resize(x, 244, 244)).transpose(1, 2, 0)
+    return np.abs(np.rint(out).astype(np.int32) - small.astype(np.int32)), np.abs(out - small)
+
+
+def test_oracle_float_resize_follows_the_same_tap_rule(oracle):
+    lv, fl = _float_resize_levels(oracle.resize_linear)
+    assert lv.max() <= 1 and fl.max() < 1.0
+    assert (lv == 0).mean() > 0.85                            # measured 0.881, largest float distance 0.77 level
+
+
+@pytest.mark.gpu
+def test_hip_float_resize_follows_the_same_tap_rule():
+    from graphite_amd import _hip
+    lv, fl = _float_resize_levels(_hip.resize_linear)
+    assert lv.max() <= 1 and fl.max() < 1.0
