@@ -53,18 +53,10 @@ WRN34_10_FLOPS_PER_IMAGE = 13317812736
 
 
 def bench_case(num_xforms, target_id=1):
-    """The stop-sign scene of SURVEY 8d (victim 14.png, target, hull 14, Points/14.csv, seed-42 transforms), prepared with
-    the product's own code only (the 244 -> 32 downsample runs on the GPU): the oracle stays out of the measured path."""
-    from cases import INP, PT14
-    from graphite_amd import _hip, transforms as T
-    from graphite_amd.imageio import load_image_chw
-    vic = load_image_chw(os.path.join(INP, "GTSRB/images/14.png"))
-    tar = load_image_chw(os.path.join(INP, "GTSRB/images/%d.png" % target_id))
-    hull = (load_image_chw(os.path.join(INP, "GTSRB/Hulls/14.png")) * 255 > 128).astype(np.float32)
-    vic_s, tar_s = _hip.resize_linear(vic, 32, 32), _hip.resize_linear(tar, 32, 32)
-    np.random.seed(42)
-    xf = T.get_transform_params(num_xforms, "GTSRB")
-    return dict(vic=vic, tar_s=tar_s, vic_s=vic_s, hull=hull, xf=xf, tab=T.build_xform_table(xf, 244, 244, PT14), pt_file=PT14)
+    """The stop-sign scene of SURVEY 8d (victim 14.png, target, hull 14, Points/14.csv, seed-42 transforms), from the
+    package alone (graphite_amd.scenes; the 244 -> 32 downsample runs on the GPU): the oracle stays out of the measured path."""
+    from graphite_amd import scenes
+    return scenes.stop_sign_scene(num_xforms, target_id)
 
 
 def extras(_hip, engine, models, synth):
@@ -76,7 +68,7 @@ def extras(_hip, engine, models, synth):
     import contextlib
     import io
     import random
-    from cases import cifar_case, INP
+    from graphite_amd.scenes import cifar_scene as cifar_case, INP, PT14
     from graphite_amd import main as gmain, parsearguments
     res = {}
     # ---- config 3
@@ -147,7 +139,6 @@ def extras(_hip, engine, models, synth):
     # the inner body of whitebox_attack.py:149-162 without the classifier; checked against the torch restatement
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import wb_reference as WR
-    from cases import PT14
     from graphite_amd import transforms as GT
     g100 = bench_case(100)
     gen = torch.Generator().manual_seed(0)
@@ -236,32 +227,62 @@ def extras(_hip, engine, models, synth):
     return res
 
 
-def spawn_ranks(n, argv):
+def visible_gpu_count():
+    """GPUs this process would see, counted WITHOUT the HIP runtime (the parent must not initialise it before it starts
+    the ranks): the *_VISIBLE_DEVICES lists if set, else the KFD topology (nodes with simd_count > 0 are GPUs)."""
+    for var in ("HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None:
+            return len([x for x in v.split(",") if x.strip() != ""])
+    import glob
+    n = 0
+    for path in glob.glob("/sys/class/kfd/kfd/topology/nodes/*/properties"):
+        try:
+            props = dict(line.split()[:2] for line in open(path) if len(line.split()) >= 2)
+            if int(props.get("simd_count", "0")) <= 0:
+                continue                                        # a CPU node
+            fd = os.open("/dev/dri/renderD%d" % int(props["drm_render_minor"]), os.O_RDWR)   # a container may hide some
+            os.close(fd)
+            n += 1
+        except (OSError, KeyError, ValueError):
+            pass
+    return n
+
+
+def spawn_ranks(n, argv, limit_s):
     """`python bench.py --gpus N` without a launcher: the parent starts N worker processes (one rank per GPU, the
-    environment torch.distributed.run would give them) BEFORE anything in it touches the GPU, waits for all of them and
-    relays rank 0's JSON line.  A failed worker ends the others and the run exits non-zero.  With fewer than N GPUs
-    visible (the 1-GPU development box) the ranks share device 0 and use gloo: a rehearsal of the sharding logic, not a
-    scaling measurement -- the line says so."""
+    environment torch.distributed.run would give them) and never touches the GPU or the HIP runtime itself; it waits for
+    all of them (at most `limit_s` seconds) and relays rank 0's JSON line.  A failed or overdue worker ends the others,
+    the failing rank's stderr tail is printed and the run exits non-zero.  With fewer than N GPUs visible (the 1-GPU
+    development box) the ranks share device 0 and use gloo: a rehearsal of the sharding logic, not a scaling
+    measurement -- the line says so."""
     import signal
     import socket
     import subprocess
-    ndev = torch.cuda.device_count()                    # does not initialise the GPU
+    import tempfile
+    ndev = visible_gpu_count()
     sock = socket.socket()
     sock.bind(("127.0.0.1", 0))
     port = sock.getsockname()[1]
     sock.close()
-    procs = []
+    procs, errs = [], []
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
                    MASTER_PORT=str(port), LOCAL_WORLD_SIZE=str(n))
         if ndev < n:
             env["GRAPHITE_BENCH_ONE_DEVICE"] = "1"
             env["GRAPHITE_BENCH_BACKEND"] = "gloo"
+        errs.append(tempfile.TemporaryFile())
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
-                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, stderr=errs[r]))
     failed = None
+    out0 = b""
     pending = set(range(n))
+    deadline = time.monotonic() + limit_s
     while pending and failed is None:
+        if time.monotonic() > deadline:
+            failed = (min(pending), "no exit within %d s" % limit_s)
+            break
         for r in sorted(pending):
             if r == 0:
                 continue
@@ -269,13 +290,13 @@ def spawn_ranks(n, argv):
             if rc is not None:
                 pending.discard(r)
                 if rc != 0:
-                    failed = (r, rc)
+                    failed = (r, "exit code %d" % rc)
         if 0 in pending:
             try:
                 out0, _ = procs[0].communicate(timeout=0.5)
                 pending.discard(0)
                 if procs[0].returncode != 0:
-                    failed = (0, procs[0].returncode)
+                    failed = (0, "exit code %d" % procs[0].returncode)
             except subprocess.TimeoutExpired:
                 pass
         else:
@@ -289,9 +310,26 @@ def spawn_ranks(n, argv):
                 p.wait(timeout=20)
             except subprocess.TimeoutExpired:
                 p.kill()
-        raise SystemExit("bench.py: rank %d exited with code %d" % failed)
+        errs[failed[0]].seek(0)
+        tail = errs[failed[0]].read().decode(errors="replace").splitlines()[-25:]
+        sys.stderr.write("bench.py: rank %d: %s; its stderr tail:\n%s\n" % (failed[0], failed[1], "\n".join(tail)))
+        raise SystemExit(1)
+    errs[0].seek(0)
+    sys.stderr.write(errs[0].read().decode(errors="replace"))
     sys.stdout.write(out0.decode())
     sys.stdout.flush()
+
+
+def ranks_seen(world, rank, dev, backend):
+    """(rank, device identity) of every rank, all-gathered: what the collective backend really connected."""
+    p = torch.cuda.get_device_properties(dev)
+    ident = {"rank": rank, "device": dev, "uuid": str(getattr(p, "uuid", "")), "pci_bus_id": getattr(p, "pci_bus_id", None),
+             "name": p.name, "pid": os.getpid()}
+    if world == 1:
+        return [ident]
+    got = [None] * world
+    dist.all_gather_object(got, ident)
+    return got
 
 
 def main():
@@ -305,6 +343,8 @@ def main():
                     help="weak-scaling variant: this many candidates per GPU instead of a fixed total")
     ap.add_argument("--transforms", type=int, default=1000)
     ap.add_argument("--chunk", type=int, default=32000, help="images per classifier launch (library default 8192); 32000 divides the 4,096,000-image job evenly for 1/2/4/8 ranks")
+    ap.add_argument("--rank-limit-s", type=int, default=1500,
+                    help="self-launched ranks (--gpus N without a launcher) are ended after this many seconds")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="skip the per-kernel HIP-event timing")
     ap.add_argument("--no-extras", action="store_true",
@@ -312,7 +352,7 @@ def main():
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
-        return spawn_ranks(args.gpus, sys.argv[1:])
+        return spawn_ranks(args.gpus, sys.argv[1:], args.rank_limit_s)
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -398,6 +438,9 @@ def main():
         "tr_queries_per_s": C_total * args.steps / dt,
         "hits_checksum": int(hits.sum().item()),
     }
+    seen = ranks_seen(world, rank, dev, backend)
+    out["ranks_seen"] = seen
+    out["distinct_devices_seen"] = len({(r["uuid"], r["pci_bus_id"]) for r in seen})
 
     if rank == 0 and prof:
         convs = {k: v for k, v in prof.items() if k.startswith("k_conv") and v["ms"] > 0}

@@ -87,13 +87,19 @@ def perform_binary_coarse_reduction(patches, err_threshold, lbl_v, lbl_t, img_t_
     tot = 0
     n = len(patches)
     # prefix unions: mask_upto(k) = union of the first k patches (the reference rebuilds it from scratch per pivot,
-    # :128-136); patches are 0/1, so the union is "running sum > 0"
-    csum = torch.cumsum(torch.stack([torch.zeros(start_mask.size()) + p for p in patches]), 0) if n else None
+    # :128-136); patches are 0/1, so the union is "running sum > 0".  The running sums are built lazily from the nearest
+    # smaller prefix already made and only the pivots actually evaluated are kept (O(log n) masks, not n).
+    prefix = {0: torch.zeros(start_mask.size())}
 
     def mask_upto(pivot):
-        if pivot <= 0:
-            return torch.zeros(start_mask.size())
-        return torch.where(csum[pivot - 1] > 0, torch.ones(start_mask.size()), torch.zeros(start_mask.size()))
+        pivot = max(0, min(int(pivot), n))
+        if pivot not in prefix:
+            q = max(k for k in prefix if k <= pivot)
+            acc = prefix[q].clone()
+            for j in range(q, pivot):
+                acc += patches[j]
+            prefix[pivot] = acc
+        return torch.where(prefix[pivot] > 0, torch.ones(start_mask.size()), torch.zeros(start_mask.size()))
 
     # A launch of ONE 100-image candidate leaves the GPU mostly idle, so with an evaluator that may speculate the pivots
     # of the next COARSE_SPEC_DEPTH levels (every outcome) are evaluated together and the search is replayed on the

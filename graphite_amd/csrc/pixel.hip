@@ -1037,7 +1037,7 @@ int px_warp_net(gr_ctx* ctx, const float* att, int H, int W, const gr_xforms* xf
         if (BW >= W) { BW = W | 1; S = W; nb = 1; }
         else { S = BW - HALO; nb = S > 0 ? (W + S - 1) / S : 0; }
         if ((size_t)H * BW > (size_t)WB_NT * WB_PRE) S = 0;
-        if (S >= 8) {
+        if (S >= 8 && nb <= 253) {               // band_of keeps a band index in one byte, 254 / 255 are sentinels
             const int cand_lo = (int)(n_begin / xf->T), cand_hi = (int)((n_begin + count - 1) / xf->T);
             const int ncand = cand_hi - cand_lo + 1;
             const size_t smem = (size_t)H * BW * 16 + tail;

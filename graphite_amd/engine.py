@@ -39,16 +39,12 @@ def allreduce_hits(hits, group=None):
     return hits
 
 
-_agreed = set()     # (group id, total, C) shapes already checked across the ranks
-
-
 def _assert_same_work(total, hits, group):
-    """First time a (total, C) shape is sharded on a group: one MAX all-reduce of (total, C, -total, -C) proves that
-    every rank is evaluating the same index space (ranks that disagree would otherwise sum unrelated counts)."""
+    """Before EVERY sharded reduction: one MAX all-reduce of (total, C, -total, -C) proves that every rank is evaluating
+    the same index space (ranks that disagree would otherwise sum unrelated counts, or pair a C-long reduction with a
+    C'-long one).  It is a fixed-size int64[4] collective, so ranks that disagree still meet in it and all of them raise;
+    it is not cached per shape -- a cache would let rank 0 skip the check that rank 1 is waiting in."""
     import torch.distributed as dist
-    key = (id(group), int(total), int(hits.numel()))
-    if key in _agreed:
-        return
     v = torch.tensor([total, hits.numel(), -total, -hits.numel()], dtype=torch.int64)
     if dist.get_backend(group) != "gloo":
         v = v.to(hits.device)
@@ -57,7 +53,6 @@ def _assert_same_work(total, hits, group):
     if not (v[0] == -v[2] == total and v[1] == -v[3] == hits.numel()):
         raise RuntimeError("sharded tr_hits: ranks disagree on the work (images max %d / min %d, candidates max %d / min %d)"
                            % (v[0], -v[2], v[1], -v[3]))
-    _agreed.add(key)
 
 
 def sharded_hits(eval_slice, total, distributed=False, group=None):

@@ -58,7 +58,7 @@ def _remove_patches(mask, score, size, interval, count):
 def _remove_pixels(mask, grad, count):
     """:222-236.  `count` times: g = mask * g; s = sum over channels (signed); s == 0 or NaN -> 999999; zero the mask at
     the FIRST minimum of s.  A removed pixel turns into 999999 and nothing else changes, so the loop is a stable sort:
-    the `count` smallest live values go, in order; once only 999999 entries are left the first of them is hit again and
+    the `count` smallest live values go, in order; once only 999999 entries are left flat index 0 is hit again and
     again (idempotent).  Returns the number of pixels whose mask changed."""
     s = torch.sum(mask * grad, dim=0)
     s = torch.where(s == 0, torch.full_like(s, 999999.0), s)
@@ -75,8 +75,10 @@ def _remove_pixels(mask, grad, count):
             flat[i] = 999999.0 if not bool((mask.flatten(1)[:, i] != 0).any()) else flat[i]
         return removed
     take = order[:min(count, live)]
-    if count > live and live < flat.numel():
-        take = torch.cat([take, order[live:live + 1]])
+    if count > live:
+        # every entry is 999999 by now, so the loop's "first minimum" is flat index 0 from here on: pixel (0, 0) loses
+        # its mask bits too (a no-op if it was live and already taken, or never in the mask)
+        take = torch.cat([take, torch.zeros(1, dtype=take.dtype, device=take.device)])
     before = int((mask.flatten(1)[0, take] > 0).sum().item())
     mask.flatten(1)[:, take] = 0
     return before

@@ -255,8 +255,24 @@ static inline void warp_pixel(const float* att, int H, int W, const double* Mi, 
     }
 }
 
+/* Margin probe (tests/pixel_margin.py): or_set_warp_nudge(n) moves every warped value n ulps (n = +-1) before
+ * the uint8 truncation below -- the one discontinuous step of the pixel path -- to measure how far a last-ulp difference
+ * between this restatement and real OpenCV could move pixels, labels and hit counts.  0 (the default) = the oracle proper. */
+static int g_warp_nudge = 0;
+void or_set_warp_nudge(int n) { g_warp_nudge = n; }
+int or_contracted_build(void) {
+#ifdef OR_FMA_CONTRACTED
+    return 1;
+#else
+    return 0;
+#endif
+}
+
 /* transforms.py:69-75: u8 = trunc(v*255); lut; (u8/255.0 as double) -> float; clip */
 static inline float gamma_stage(float v, const uint8_t* lut) {
+    for (int n = g_warp_nudge; n > 0; n--) v = nextafterf(v, INFINITY);
+    for (int n = g_warp_nudge; n < 0; n++) v = nextafterf(v, -INFINITY);
+    if (v < 0.f) v = 0.f;                /* a nudge below 0 would wrap in the byte cast; OpenCV inputs are clipped to [0,1] */
     float s = v * 255.0f;
     int u = (int)s;                      /* astype(uint8) of a value in [0,256) */
     u &= 255;

@@ -76,6 +76,12 @@ int or_wrn_forward(const float* const* tensors, int ntensors, int depth, int wid
 /* torch.max(out,1) first-max argmax; hits[c] += (pred == target) over the T images of candidate c. */
 int or_argmax_hits(const float* logits, int N, int ncls, int T, int target, int64_t* preds, int32_t* hits);
 
+/* Margin probes, never used by the parity tests proper (tests/pixel_margin.py): move every warped value n ulps before the
+ * uint8 truncation of transforms.py:69; and whether this library is the FMA-contracted build (libgraphite_oracle_fma.so:
+ * the same source compiled with -ffp-contract=fast, as OpenCV's AVX2 v_muladd / v_fma filter and resize paths round). */
+void or_set_warp_nudge(int n);
+int or_contracted_build(void);
+
 #ifdef __cplusplus
 }
 #endif

@@ -5,7 +5,7 @@ import contextlib, io, os, random, sys, time
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in (R, R + "/tests"): sys.path.insert(0, p)
 import numpy as np, torch
-from cases import INP
+from graphite_amd.scenes import INP
 from graphite_amd import main as gmain, models, parsearguments, synth
 a = parsearguments.getarguments(["-v", "14", "-t", "27", "--tr_lo", "0.65", "--tr_hi", "0.85", "-m", "100", "-b", "100", "--coarse_mode", "binary", "--seed", "42"])
 model = models.GTSRBNet(); model.load_state_dict(synth.gtsrb_state_dict(readout="toy3"))

@@ -93,7 +93,7 @@ import pg_transforms as ref_pg                           # noqa: E402
 
 from graphite_amd import synth                           # noqa: E402
 
-INP = os.path.join(HERE, "inputs")
+INP = os.path.join(os.path.dirname(os.path.dirname(HERE)), "graphite_amd", "data", "inputs")
 
 
 def xf_array(xf):

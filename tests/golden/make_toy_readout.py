@@ -27,7 +27,7 @@ import oracle_lib as O                                   # noqa: E402
 from graphite_amd import synth, transforms as T, weights  # noqa: E402
 from graphite_amd.imageio import load_image_chw           # noqa: E402
 
-INP = os.path.join(HERE, "inputs")
+INP = os.path.join(os.path.dirname(os.path.dirname(HERE)), "graphite_amd", "data", "inputs")
 OUT = os.path.join(REPO, "graphite_amd", "data")
 PT14 = os.path.join(INP, "GTSRB/Points/14.csv")
 CLASSES = (14, 1, 27)

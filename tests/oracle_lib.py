@@ -3,6 +3,7 @@
 TEST INFRASTRUCTURE: imported by tests/, __graft_entry__.smoke() and bench.py's
 cpu_baseline leg only.  The product package (graphite_amd/) never imports this.
 """
+import contextlib
 import ctypes as C
 import os
 import subprocess
@@ -30,6 +31,29 @@ def lib():
             build()
         _lib = C.CDLL(_SO)
     return _lib
+
+
+@contextlib.contextmanager
+def variant(fma=False, nudge=0):
+    """Margin probes (tests/pixel_margin.py): inside the block every call goes to the FMA-contracted build of the same
+    source (-ffp-contract=fast) and / or moves each warped value `nudge` ulps before the uint8 truncation."""
+    global _lib
+    base = lib()
+    if fma:
+        path = os.path.join(_ORACLE_DIR, "libgraphite_oracle_fma.so")
+        if not os.path.exists(path):
+            build()
+        L = C.CDLL(path)
+        assert L.or_contracted_build() == 1 and base.or_contracted_build() == 0
+    else:
+        L = base
+    L.or_set_warp_nudge(int(nudge))
+    _lib = L
+    try:
+        yield L
+    finally:
+        L.or_set_warp_nudge(0)
+        _lib = base
 
 
 def _f(a):

@@ -75,7 +75,10 @@ def _disagree_worker(rank, world, port, q):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    C = 4 + rank                                            # rank 1 believes there is one more candidate
+    # first an agreeing call of shape A on both ranks (a per-shape cache of the check would now hold A on both) ...
+    engine.sharded_hits(lambda b, c: torch.zeros(4, dtype=torch.int32), 40, distributed=True)
+    # ... then rank 0 repeats A while rank 1 believes there is one more candidate: the check runs on EVERY call
+    C = 4 + rank
     try:
         engine.sharded_hits(lambda b, c: torch.zeros(C, dtype=torch.int32), C * 10, distributed=True)
         q.put((rank, "no error"))

@@ -56,3 +56,43 @@ def test_convert2networkwb_matches_interpolate():
     y = T.convert2NetworkWB(x)
     assert y.shape == (2, 3, 32, 32) and float(y.min()) >= 0 and float(y.max()) <= 1
     assert torch.equal(T.convert2NetworkWB(x[0]), y[0])
+
+
+def _literal_pixel_loop(mask, grad, count):
+    """whitebox/whitebox_attack.py:223-235 written out literally (CPU tensors)."""
+    ref_mask, fg = mask.clone(), grad.clone()
+    for _ in range(count):
+        fg = ref_mask * fg
+        s = torch.sum(fg, dim=0)
+        s = torch.where(s == 0, torch.tensor(999999).float(), s)
+        s[torch.isnan(s)] = 999999
+        idx = (s == torch.min(s)).nonzero()[0]
+        for c in range(3):
+            ref_mask[(c,) + tuple(idx)] = 0
+    return ref_mask
+
+
+def test_remove_pixels_closed_form_equals_the_reference_loop():
+    """Includes the case the round-2 review found: count > live pixels.  Once every entry is the 999999 sentinel the loop
+    keeps hitting flat index 0, so pixel (0, 0) loses its mask bits -- whether it was live, a zero-gradient masked pixel
+    or a NaN one -- and no other sentinel pixel does."""
+    from graphite_amd.whitebox_attack import _remove_pixels
+    g = torch.Generator().manual_seed(3)
+    for case in range(8):
+        mask = (torch.rand(1, 12, 15, generator=g) > 0.4).float().repeat(3, 1, 1)
+        grad = torch.randn(3, 12, 15, generator=g)
+        grad[:, 2, 3] = 0.0                                   # a live pixel with a zero sum
+        grad[0, 5, 5] = float("nan")
+        if case >= 3:
+            mask[:, 0, 0] = 1.0                               # (0, 0) inside the mask ...
+            mask[:, 0, 1] = 1.0
+            grad[:, 0, 1] = 0.0                               # ... and a masked zero-gradient pixel right after it
+        if case in (4, 6):
+            grad[:, 0, 0] = 0.0                               # (0, 0) masked with a zero gradient sum: a sentinel from the start
+        if case in (5, 7):
+            grad[1, 0, 0] = float("nan")
+        count = (7, 60, 400, 400, 400, 400, 1, 123)[case]
+        want = _literal_pixel_loop(mask, grad, count)
+        got = mask.clone()
+        _remove_pixels(got, grad, count)
+        assert torch.equal(got, want), case
