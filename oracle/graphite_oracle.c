@@ -637,3 +637,250 @@ int or_argmax_hits(const float* logits, int N, int ncls, int T, int target, int6
     }
     return 0;
 }
+
+/* ==========================================================================================
+ * PatchGuard robust classifier (reference patchguard/patchguard_predict.py:21-53).
+ *
+ *   z = (x + 0.5) * 255                                  :42     reference code
+ *   z = F.interpolate(z, 192, mode='bicubic') / 255      :43     reference code (torch's bicubic, A = -0.75, half-pixel
+ *                                                                centres, border taps clamped)
+ *   z = Normalize(mean, std)(z)                          :30-32,44  reference code
+ *   local = bagnet17(aggregation='none')(z)              :24,44  THIRD PARTY (inspire-group/PatchGuard @ ae23629, nets/bagnet.py
+ *                                                                = Brendel & Bethge's BagNet with the fc applied per position);
+ *                                                                source and weights absent: restated from the published
+ *                                                                architecture, "parity unpinned"
+ *   pred = masking_defense(local[i], thres=0.0, window_shape=[6,6])   :48  THIRD PARTY (utils/defense_utils.py): restated
+ *                                                                from PatchGuard (Xiang et al., USENIX Security 2021)
+ *                                                                Algorithm 1 "robust masking", "parity unpinned"
+ * ========================================================================================== */
+
+/* torch upsample_bicubic2d (ATen UpSample.h): cubic_convolution1/2 and get_cubic_upsample_coefficients, A = -0.75 */
+static inline float pg_cc1(float x, float A) { return ((A + 2.f) * x - (A + 3.f)) * x * x + 1.f; }
+static inline float pg_cc2(float x, float A) { return ((A * x - 5.f * A) * x + 8.f * A) * x - 4.f * A; }
+typedef struct { int i[4]; float w[4]; } pg_tap_t;
+static void pg_taps(int ssize, int dsize, pg_tap_t* t) {
+    const float A = -0.75f;
+    const float scale = (float)ssize / (float)dsize;          /* area_pixel_compute_scale, align_corners=False, no scale_factor */
+    for (int d = 0; d < dsize; d++) {
+        float real = scale * ((float)d + 0.5f) - 0.5f;        /* area_pixel_compute_source_index(cubic=true): not clamped at 0 */
+        float fl = floorf(real);
+        int in = (int)fl;
+        float lam = real - fl;
+        lam = lam < 0.f ? 0.f : (lam > 1.f ? 1.f : lam);      /* guard_index_and_lambda */
+        t[d].w[0] = pg_cc2(lam + 1.f, A);
+        t[d].w[1] = pg_cc1(lam, A);
+        float l2 = 1.f - lam;
+        t[d].w[2] = pg_cc1(l2, A);
+        t[d].w[3] = pg_cc2(l2 + 1.f, A);
+        for (int j = 0; j < 4; j++) {
+            int q = in - 1 + j;
+            t[d].i[j] = q < 0 ? 0 : (q > ssize - 1 ? ssize - 1 : q);          /* upsample_get_value_bounded */
+        }
+    }
+}
+
+static const float PG_MEAN[3] = {0.4914f, 0.4822f, 0.4465f};   /* patchguard_predict.py:31 */
+static const float PG_STD[3] = {0.2023f, 0.1994f, 0.2010f};
+
+/* one output value: rows combined left to right, then the four row results top to bottom (cubic_interp1d order) */
+static inline float pg_sample(const float* plane, int S, const pg_tap_t* ty, const pg_tap_t* tx) {
+    float acc = 0.f;
+    for (int j = 0; j < 4; j++) {
+        const float* r = plane + (size_t)ty->i[j] * S;
+        float h = 0.f;
+        for (int i = 0; i < 4; i++) {
+            float v = (r[tx->i[i]] + 0.5f) * 255.f;           /* :42 */
+            h = i == 0 ? v * tx->w[0] : h + v * tx->w[i];
+        }
+        acc = j == 0 ? h * ty->w[0] : acc + h * ty->w[j];
+    }
+    return acc;
+}
+
+/* x [N,3,S,S] in [-0.5,0.5] -> out [N,3,D,D]: lines 42-44 + the Normalize of :30-32 */
+int or_pg_preprocess(const float* x, int N, int S, int D, float* out, int nthreads) {
+    if (!x || !out || N < 0 || S <= 0 || D <= 0) return -1;
+    pg_tap_t* t = (pg_tap_t*)malloc(sizeof(pg_tap_t) * D);
+    pg_taps(S, D, t);
+    if (nthreads < 1) nthreads = 1;
+#pragma omp parallel for num_threads(nthreads) schedule(static)
+    for (int nc = 0; nc < N * 3; nc++) {
+        const int c = nc % 3;
+        const float* plane = x + (size_t)nc * S * S;
+        float* o = out + (size_t)nc * D * D;
+        for (int dy = 0; dy < D; dy++)
+            for (int dx = 0; dx < D; dx++) {
+                float v = pg_sample(plane, S, &t[dy], &t[dx]) / 255.f;        /* :43 */
+                o[(size_t)dy * D + dx] = (v - PG_MEAN[c]) / PG_STD[c];        /* Normalize: sub_(mean).div_(std) */
+            }
+    }
+    free(t);
+    return 0;
+}
+
+/* ---- BagNet (nets/bagnet.py of the PatchGuard repository = bagnets/pytorchnet.py, restated) -----------------------
+ * conv1 1x1 3->64, conv2 3x3 64->64 (no padding), bn1, relu; four stages of Bottleneck blocks (planes 64/128/256/512,
+ * expansion 4): conv1 1x1 -> bn -> relu -> conv2 kxk stride s NO padding -> bn -> relu -> conv3 1x1 -> bn; the
+ * residual (1x1 stride-s conv + bn "downsample" in the first block of a stage, identity otherwise) is cropped at the
+ * bottom/right to the output's size ([:, :, :-diff, :-diff]) before the add; relu.  k = 3 in block i of stage g iff
+ * kernel3[g] > i; the stage stride sits on block 0's conv2.  bagnet17: layers [3,4,6,3], strides [2,2,2,1], kernel3
+ * [1,1,1,0]: receptive field 17, stride 8 (patchguard_predict.py:33-34).  aggregation='none': the fc is applied at every
+ * position -> local logits [h, w, ncls].
+ * Eval BatchNorm is FOLDED into the preceding conv here and in the HIP library (w' = w * scale[co] in float32, bias' =
+ * shift[co]): one fmaf chain per output, then + bias', + residual, ReLU -- so that the two compare bit for bit; against
+ * a plain PyTorch forward of the same architecture the difference is rounding (tests: 1e-4 relative). */
+typedef struct { float *w1, *b1, *w2, *b2, *w3, *b3, *wd, *bd; int cin, planes, k, stride; } bag_block_t;
+
+static float* fold_conv_bn(const float* w, int Co, int Ci, int KH, int KW, const float* bw, const float* bb, const float* bm,
+                           const float* bv, float** bias_out) {
+    bn_t bn = bn_fold(bw, bb, bm, bv, Co);
+    float* scaled = (float*)malloc(sizeof(float) * (size_t)Co * Ci * KH * KW);
+    for (int o = 0; o < Co; o++)
+        for (size_t e = 0; e < (size_t)Ci * KH * KW; e++) scaled[(size_t)o * Ci * KH * KW + e] = w[(size_t)o * Ci * KH * KW + e] * bn.scale[o];
+    float* p = repack_oihw(scaled, Co, Ci, KH, KW);
+    free(scaled); free(bn.scale);
+    *bias_out = bn.shift;
+    return p;
+}
+
+/* spatial size of the local-logit map for a D x D input */
+int or_bagnet_out_size(int D, const int* layers, const int* strides, const int* kernel3) {
+    int H = D - 2;                                            /* conv2, 3x3 no padding */
+    for (int g = 0; g < 4; g++)
+        for (int i = 0; i < layers[g]; i++) {
+            int k = kernel3[g] > i ? 3 : 1, s = i == 0 ? strides[g] : 1;
+            H = (H - k) / s + 1;
+        }
+    return H;
+}
+
+int or_bagnet_forward(const float* const* t, int nt, const int* layers, const int* strides, const int* kernel3, int ncls,
+                      const float* z, int N, int D, float* local, int nthreads) {
+    if (!t || !layers || !strides || !kernel3 || !z || !local || N < 0 || D < 8 || ncls < 1 || ncls > 1024) return -1;
+    int ti = 0;
+    const float* wc1 = t[ti++];                               /* conv1.weight [64,3,1,1] */
+    float *bc2, *wc2 = fold_conv_bn(t[ti], 64, 64, 3, 3, t[ti + 1], t[ti + 2], t[ti + 3], t[ti + 4], &bc2); ti += 5;
+    int nb = layers[0] + layers[1] + layers[2] + layers[3];
+    bag_block_t* blk = (bag_block_t*)calloc(nb, sizeof(bag_block_t));
+    int inpl = 64, bi = 0;
+    for (int g = 0; g < 4; g++)
+        for (int i = 0; i < layers[g]; i++, bi++) {
+            bag_block_t* b = &blk[bi];
+            b->planes = 64 << g; b->cin = inpl; b->k = kernel3[g] > i ? 3 : 1; b->stride = i == 0 ? strides[g] : 1;
+            b->w1 = fold_conv_bn(t[ti], b->planes, b->cin, 1, 1, t[ti + 1], t[ti + 2], t[ti + 3], t[ti + 4], &b->b1); ti += 5;
+            b->w2 = fold_conv_bn(t[ti], b->planes, b->planes, b->k, b->k, t[ti + 1], t[ti + 2], t[ti + 3], t[ti + 4], &b->b2); ti += 5;
+            b->w3 = fold_conv_bn(t[ti], 4 * b->planes, b->planes, 1, 1, t[ti + 1], t[ti + 2], t[ti + 3], t[ti + 4], &b->b3); ti += 5;
+            if (i == 0) {                                     /* stride != 1 or inplanes != planes * 4: always true for block 0 */
+                b->wd = fold_conv_bn(t[ti], 4 * b->planes, b->cin, 1, 1, t[ti + 1], t[ti + 2], t[ti + 3], t[ti + 4], &b->bd); ti += 5;
+            }
+            inpl = 4 * b->planes;
+        }
+    if (ti + 2 != nt) { free(blk); return -3; }
+    float* wfc = repack_oihw(t[ti], ncls, inpl, 1, 1);
+    const float* bfc = t[ti + 1];
+    size_t big = (size_t)D * D * 64;
+    { int H = D - 2;
+      for (int q = 0; q < nb; q++) { size_t a = (size_t)H * H * 4 * blk[q].planes; if (a > big) big = a;
+                                     H = (H - blk[q].k) / blk[q].stride + 1; } }
+    if (nthreads < 1) nthreads = 1;
+    const int Hl = or_bagnet_out_size(D, layers, strides, kernel3);
+#pragma omp parallel num_threads(nthreads)
+    {
+        float* X = (float*)malloc(sizeof(float) * big);
+        float* T1 = (float*)malloc(sizeof(float) * big);
+        float* T2 = (float*)malloc(sizeof(float) * big);
+        float* R = (float*)malloc(sizeof(float) * big);
+#pragma omp for schedule(dynamic, 1)
+        for (int n = 0; n < N; n++) {
+            const float* zi = z + (size_t)n * 3 * D * D;
+            for (int p = 0; p < D * D; p++)                   /* conv1: 1x1, 3 -> 64, no bias, no BN, no ReLU */
+                for (int o = 0; o < 64; o++) {
+                    float acc = 0.f;
+                    for (int c = 0; c < 3; c++) acc = fmaf(zi[(size_t)c * D * D + p], wc1[o * 3 + c], acc);
+                    T1[(size_t)p * 64 + o] = acc;
+                }
+            int H = D - 2;
+            conv_nhwc(T1, D, D, 64, wc2, 3, 3, 1, 0, X, H, H, 64); bias_relu(X, (size_t)H * H, 64, bc2, 1);
+            for (int q = 0; q < nb; q++) {
+                bag_block_t* b = &blk[q];
+                int Ho = (H - b->k) / b->stride + 1, Co = 4 * b->planes;
+                conv_nhwc(X, H, H, b->cin, b->w1, 1, 1, 1, 0, T1, H, H, b->planes); bias_relu(T1, (size_t)H * H, b->planes, b->b1, 1);
+                conv_nhwc(T1, H, H, b->planes, b->w2, b->k, b->k, b->stride, 0, T2, Ho, Ho, b->planes);
+                bias_relu(T2, (size_t)Ho * Ho, b->planes, b->b2, 1);
+                const float* res; int rstride;               /* residual rows are rstride pixels apart (cropped view) */
+                if (b->wd) {                                  /* only the Ho x Ho corner that survives the crop is computed */
+                    conv_nhwc(X, H, H, b->cin, b->wd, 1, 1, b->stride, 0, R, Ho, Ho, Co); bias_relu(R, (size_t)Ho * Ho, Co, b->bd, 0);
+                    res = R; rstride = Ho;
+                } else { res = X; rstride = H; }
+                conv_nhwc(T2, Ho, Ho, b->planes, b->w3, 1, 1, 1, 0, T1, Ho, Ho, Co);
+                for (int y = 0; y < Ho; y++)
+                    for (int x2 = 0; x2 < Ho; x2++)
+                        for (int o = 0; o < Co; o++) {
+                            float v = T1[((size_t)y * Ho + x2) * Co + o] + b->b3[o];
+                            v = v + res[((size_t)y * rstride + x2) * Co + o];
+                            T1[((size_t)y * Ho + x2) * Co + o] = v > 0.f ? v : 0.f;
+                        }
+                float* tmp = X; X = T1; T1 = tmp;
+                H = Ho;
+            }
+            conv_nhwc(X, H, H, inpl, wfc, 1, 1, 1, 0, T1, H, H, ncls);      /* x.permute(0,2,3,1); fc(x) */
+            float* lo = local + (size_t)n * Hl * Hl * ncls;
+            for (size_t p = 0; p < (size_t)H * H; p++)
+                for (int c = 0; c < ncls; c++) lo[p * ncls + c] = T1[p * ncls + c] + bfc[c];
+        }
+        free(X); free(T1); free(T2); free(R);
+    }
+    free(wc2); free(bc2); free(wfc);
+    for (int q = 0; q < nb; q++) {
+        free(blk[q].w1); free(blk[q].b1); free(blk[q].w2); free(blk[q].b2); free(blk[q].w3); free(blk[q].b3);
+        free(blk[q].wd); free(blk[q].bd);
+    }
+    free(blk);
+    return 0;
+}
+
+/* ---- masking_defense(local_feature, thres, window_shape)  [THIRD PARTY, restated from the paper's Algorithm 1, unpinned] ----
+ *   u = clip(local, 0, inf)                                        (clipping = -1 -> [0, inf))
+ *   for every class c: total_c = sum u[:,:,c]; win_c = max over all window positions of sum u[x:x+wx, y:y+wy, c]
+ *                      masked_c = total_c - win_c   if win_c / total_c > thres   (0/0 = nan -> not masked), else total_c
+ *   prediction = LAST index of the maximum of masked (np.argsort(kind='stable')[-1])
+ * Sums are float32, row-major (x outer, y inner), one chain per (window, class) -- the order the HIP kernel uses.
+ * scores [N,ncls] = masked class evidence; preds [N]. */
+int or_masking_defense(const float* local, int N, int h, int w, int ncls, int wx, int wy, float thres, float* scores,
+                       int64_t* preds) {
+    if (!local || N < 0 || h <= 0 || w <= 0 || ncls <= 0 || wx <= 0 || wy <= 0 || wx > h || wy > w) return -1;
+    for (int n = 0; n < N; n++) {
+        const float* u = local + (size_t)n * h * w * ncls;
+        int best = 0; float bv = 0.f;
+        for (int c = 0; c < ncls; c++) {
+            float total = 0.f;
+            for (int p = 0; p < h * w; p++) { float v = u[(size_t)p * ncls + c]; total += v > 0.f ? v : 0.f; }
+            float win = -INFINITY;
+            for (int x = 0; x + wx <= h; x++)
+                for (int y = 0; y + wy <= w; y++) {
+                    float s = 0.f;
+                    for (int i = 0; i < wx; i++)
+                        for (int j = 0; j < wy; j++) { float v = u[((size_t)(x + i) * w + y + j) * ncls + c]; s += v > 0.f ? v : 0.f; }
+                    if (s > win) win = s;
+                }
+            float m = (win / total > thres) ? total - win : total;
+            if (scores) scores[(size_t)n * ncls + c] = m;
+            if (c == 0 || m >= bv) { bv = m; best = c; }
+        }
+        if (preds) preds[n] = best;
+    }
+    return 0;
+}
+
+/* PatchGuardNoDefense (patchguard_predict.py:56-89): aggregation='mean' over the positions, then np.argmax (first maximum).
+ * scores [N,ncls] = sequential row-major float32 sum * (1 / (h*w)). */
+int or_pg_mean_logits(const float* local, int N, int h, int w, int ncls, float* scores) {
+    if (!local || !scores || N < 0 || h <= 0 || w <= 0 || ncls <= 0) return -1;
+    for (int n = 0; n < N; n++)
+        for (int c = 0; c < ncls; c++) {
+            float s = 0.f;
+            for (int p = 0; p < h * w; p++) s += local[((size_t)n * h * w + p) * ncls + c];
+            scores[(size_t)n * ncls + c] = s * (1.0f / (float)(h * w));
+        }
+    return 0;
+}

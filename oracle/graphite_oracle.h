@@ -76,6 +76,23 @@ int or_wrn_forward(const float* const* tensors, int ntensors, int depth, int wid
 /* torch.max(out,1) first-max argmax; hits[c] += (pred == target) over the T images of candidate c. */
 int or_argmax_hits(const float* logits, int N, int ncls, int T, int target, int64_t* preds, int32_t* hits);
 
+/* PatchGuard robust classifier, patchguard/patchguard_predict.py:21-53 (see graphite_oracle.c for what is reference code
+ * and what is restated third-party code).
+ * or_pg_preprocess: x [N,3,S,S] in [-0.5,0.5] -> (x+0.5)*255 -> torch bicubic to D x D -> /255 -> Normalize -> [N,3,D,D].
+ * or_bagnet_forward: tensors (PyTorch layouts) = conv1.weight, conv2.weight, bn1.{weight,bias,running_mean,running_var};
+ *   per stage g = 0..3, block i: conv1.weight, bn1.{4}, conv2.weight, bn2.{4}, conv3.weight, bn3.{4},
+ *   [downsample.0.weight, downsample.1.{4} for i == 0]; fc.weight, fc.bias.  z [N,3,D,D] -> local [N,h,h,ncls],
+ *   h = or_bagnet_out_size(D, ...).
+ * or_masking_defense / or_pg_mean_logits: local [N,h,w,ncls] -> scores [N,ncls] (+ preds with the last-maximum rule of
+ *   np.argsort(kind='stable')[-1]; the no-defense variant is argmax'd with the first-maximum rule by or_argmax_hits). */
+int or_pg_preprocess(const float* x, int N, int S, int D, float* out, int nthreads);
+int or_bagnet_out_size(int D, const int* layers, const int* strides, const int* kernel3);
+int or_bagnet_forward(const float* const* tensors, int ntensors, const int* layers, const int* strides, const int* kernel3,
+                      int num_classes, const float* z, int N, int D, float* local, int nthreads);
+int or_masking_defense(const float* local, int N, int h, int w, int ncls, int wx, int wy, float thres, float* scores,
+                       int64_t* preds);
+int or_pg_mean_logits(const float* local, int N, int h, int w, int ncls, float* scores);
+
 /* Margin probes, never used by the parity tests proper (tests/pixel_margin.py): move every warped value n ulps before the
  * uint8 truncation of transforms.py:69; and whether this library is the FMA-contracted build (libgraphite_oracle_fma.so:
  * the same source compiled with -ffp-contract=fast, as OpenCV's AVX2 v_muladd / v_fma filter and resize paths round). */

@@ -129,3 +129,41 @@ def test_oracle_batch_shapes_and_ranges(oracle):
     out = oracle.warp_batch(c["vic"], c["hull"][None], ((c["tar_s"] - c["vic_s"]) * c["hull"])[None], c["tab"][:12],
                             normalize=False)
     assert out.min() >= 0 and out.max() <= 1.0
+
+
+def test_oracle_warp_geometry_against_torch_grid_sample(oracle):
+    """Independent geometry check of the warp restatement (perspective_transform.py:47): the same homography sampled by
+    torch's grid_sample (float64, pixel-index coordinates = align_corners=True, border padding = BORDER_REPLICATE)
+    without OpenCV's 1/32-px coordinate rounding.  cvRound to 1/32 px displaces a tap by <= 1/64 px per axis, which moves
+    a bilinear sample by at most (1/64 + 1/64) x the largest step between neighbouring pixels around the tap."""
+    import torch
+    import torch.nn.functional as F
+    for case, tsel in ((gtsrb_case(), range(0, 100, 3)), (cifar_case(), range(0, 100, 9))):
+        att = case["vic"]
+        _, H, W = att.shape
+        img = torch.from_numpy(att).double()[None]
+        # largest difference to any 8-neighbour, dilated once more so that it covers all four taps of a sample
+        pad = F.pad(img, (1, 1, 1, 1), mode="replicate")
+        step = torch.zeros_like(img)
+        for dy in range(3):
+            for dx in range(3):
+                step = torch.maximum(step, (pad[:, :, dy:dy + H, dx:dx + W] - img).abs())
+        step = F.max_pool2d(step, 3, 1, 1)
+        worst = 0.0
+        for t in tsel:
+            xf = case["tab"][t]
+            cx, cy = int(xf["crop_x"]), int(xf["crop_y"])
+            _, warped = oracle.warp_one(att, xf, normalize=case["pt_file"] is not None, want_warped=True)
+            Mi = np.linalg.inv(xf["M"].reshape(3, 3))
+            ys, xs = np.mgrid[0:cy, 0:cx].astype(np.float64)
+            den = Mi[2, 0] * xs + Mi[2, 1] * ys + Mi[2, 2]
+            sx = (Mi[0, 0] * xs + Mi[0, 1] * ys + Mi[0, 2]) / den
+            sy = (Mi[1, 0] * xs + Mi[1, 1] * ys + Mi[1, 2]) / den
+            grid = torch.from_numpy(np.stack([2 * sx / (W - 1) - 1, 2 * sy / (H - 1) - 1], -1))[None]
+            ref = F.grid_sample(img, grid, mode="bilinear", padding_mode="border", align_corners=True)[0].numpy()
+            near = F.grid_sample(step, grid, mode="nearest", padding_mode="border", align_corners=True)[0].numpy()
+            err = np.abs(warped - ref)
+            assert (err <= near / 32.0 + 2e-6).all(), (t, float((err - near / 32.0).max()))
+            worst = max(worst, float(err.max()))
+        assert worst > 1e-5              # the two samplers are NOT the same code: the quantisation is visible ...
+        assert worst < 0.1               # ... and small
