@@ -54,6 +54,12 @@ SIGNATURES = {
     "gr_model_set_bf16_layers": (_i, [_vp, C.c_uint]),
     "gr_model_forward": (_i, [_vp, _vp, _vp, _i, _vp, _vp]),
     "gr_model_predict": (_i, [_vp, _vp, _vp, _i, _vp, _vp]),
+    "gr_pg_preprocess": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp]),
+    "gr_model_load_bagnet": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _vp, _i, _i, C.POINTER(_vp)]),
+    "gr_pg_configure": (_i, [_vp, _i, _i, _f]),
+    "gr_pg_out_size": (_i, [_vp]),
+    "gr_pg_local_logits": (_i, [_vp, _vp, _vp, _i, _vp, _vp]),
+    "gr_pg_masking_defense": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _f, _vp, _vp, _vp]),
     "gr_model_input_grad": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp, _vp]),
     "gr_tr_hits": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp, _i, _i, _i, _vp, _f, _i, _i, _i64, _i64, _vp, _vp, _vp, _vp]),
     "gr_wb_forward": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp, _i, _i, _vp, _vp]),
@@ -330,9 +336,11 @@ def warp_batch(img, masks, thetas, tab, lbd, normalize, net=32):
 # classifiers
 # ------------------------------------------------------------------------------------------------
 class Model:
-    """gr_model handle.  `kind` = 'gtsrb' (20 tensors) or 'wrn' (see weights.wrn_tensor_list)."""
+    """gr_model handle.  `kind` = 'gtsrb' (20 tensors), 'wrn' (see weights.wrn_tensor_list) or 'bagnet' (the PatchGuard
+    classifier: weights.bagnet_tensor_list; layers / strides / kernel3 / upsample as gr_model_load_bagnet)."""
 
-    def __init__(self, kind, tensors, depth=34, widen=10, num_classes=10):
+    def __init__(self, kind, tensors, depth=34, widen=10, num_classes=10, layers=(3, 4, 6, 3), strides=(2, 2, 2, 1),
+                 kernel3=(1, 1, 1, 0), upsample=192):
         lib = load_library()
         self._ctx = ctx()
         keep = [np.ascontiguousarray(t, dtype=np.float32) for t in tensors]
@@ -344,6 +352,10 @@ class Model:
             rc = lib.gr_model_load_gtsrb(self._ctx, ptrs, numel, len(keep), C.byref(self._h))
         elif kind == "wrn":
             rc = lib.gr_model_load_wrn(self._ctx, ptrs, numel, len(keep), depth, widen, num_classes, C.byref(self._h))
+        elif kind == "bagnet":
+            i4 = [(C.c_int * 4)(*[int(v) for v in a]) for a in (layers, strides, kernel3)]
+            rc = lib.gr_model_load_bagnet(self._ctx, ptrs, numel, len(keep), i4[0], i4[1], i4[2], num_classes, int(upsample),
+                                          C.byref(self._h))
         else:
             raise ValueError(kind)
         _check(self._ctx, rc, f"gr_model_load_{kind}")
@@ -392,6 +404,22 @@ class Model:
                "gr_model_forward")
         return out
 
+    # ---- PatchGuard models only ----
+    def pg_configure(self, defense=True, window=6, thres=0.0):
+        _check(self._ctx, load_library().gr_pg_configure(self._h, int(bool(defense)), int(window), float(thres)), "gr_pg_configure")
+
+    @property
+    def pg_out_size(self):
+        return int(load_library().gr_pg_out_size(self._h))
+
+    def pg_local_logits(self, x):
+        """x [N,3,32,32] in [-0.5,0.5] -> local logits CUDA tensor [N,h,h,ncls] (patchguard_predict.py:42-44)."""
+        xd = to_dev(x)
+        n, h = xd.shape[0], self.pg_out_size
+        out = torch.empty((n, h, h, self.num_classes), device=xd.device, dtype=torch.float32)
+        _check(self._ctx, load_library().gr_pg_local_logits(self._ctx, self._h, _p(xd), n, _p(out), _stream()), "gr_pg_local_logits")
+        return out
+
     def predict_dev(self, x):
         xd = to_dev(x)
         n = xd.shape[0]
@@ -399,6 +427,27 @@ class Model:
         _check(self._ctx, load_library().gr_model_predict(self._ctx, self._h, _p(xd), n, _p(out), _stream()),
                "gr_model_predict")
         return out
+
+
+def pg_preprocess(x, size=192):
+    """patchguard_predict.py:42-44 + :30-32: x [N,3,S,S] in [-0.5,0.5] -> normalised CUDA tensor [N,3,size,size]."""
+    xd = to_dev(x)
+    n, _, s, s2 = xd.shape
+    assert s == s2
+    out = torch.empty((n, 3, size, size), device=xd.device, dtype=torch.float32)
+    _check(ctx(), load_library().gr_pg_preprocess(ctx(), _p(xd), n, s, int(size), _p(out), _stream()), "gr_pg_preprocess")
+    return out
+
+
+def pg_masking_defense(local, window=6, thres=0.0):
+    """masking_defense (patchguard_predict.py:48) for a batch of local logits [N,h,w,ncls] -> (scores [N,ncls], preds [N])."""
+    ld = to_dev(local)
+    n, h, w, ncls = ld.shape
+    scores = torch.empty((n, ncls), device=ld.device, dtype=torch.float32)
+    preds = torch.empty((n,), device=ld.device, dtype=torch.int64)
+    _check(ctx(), load_library().gr_pg_masking_defense(ctx(), _p(ld), n, h, w, ncls, int(window), float(thres), _p(scores),
+                                                       _p(preds), _stream()), "gr_pg_masking_defense")
+    return scores, preds
 
 
 def tr_hits_dev(model, img, masks, thetas, tab, lbd, normalize, target, img_begin=0, img_count=None,

@@ -468,7 +468,37 @@ extern "C" int gr_model_predict(gr_ctx* ctx, gr_model* m, const float* x, int N,
     for (int n0 = 0; n0 < N; n0 += chunk) {
         int nb = N - n0 < chunk ? N - n0 : chunk;
         if ((rc = net_forward(ctx, m, x + (size_t)n0 * 3072, nb, lg, ctx->ws + lg_bytes, ctx->ws_bytes - lg_bytes, st))) return rc;
-        if ((rc = net_argmax(ctx, lg, nb, ncls, preds + n0, st))) return rc;
+        if ((rc = net_argmax(ctx, lg, nb, ncls, preds + n0, st, net_tie_last(m)))) return rc;
+    }
+    return GR_OK;
+}
+
+// ---- PatchGuard robust classifier (patchguard/patchguard_predict.py) ----
+extern "C" int gr_pg_preprocess(gr_ctx* ctx, const float* x, int N, int S, int D, float* out, void* stream) {
+    NEED_CTX();
+    if (!x || !out || N < 0) return gr_fail(ctx, GR_EINVAL, "gr_pg_preprocess: bad arguments");
+    return pg_preprocess(ctx, x, N, S, D, false, nullptr, out, (hipStream_t)stream);
+}
+extern "C" int gr_pg_masking_defense(gr_ctx* ctx, const float* local, int N, int h, int w, int ncls, int window, float thres,
+                                     float* scores, int64_t* preds, void* stream) {
+    NEED_CTX();
+    if (!local || N < 0 || (!scores && !preds)) return gr_fail(ctx, GR_EINVAL, "gr_pg_masking_defense: bad arguments");
+    return pg_masking(ctx, local, N, h, w, ncls, window, window, thres, scores, preds, (hipStream_t)stream);
+}
+extern "C" int gr_pg_local_logits(gr_ctx* ctx, gr_model* m, const float* x, int N, float* local, void* stream) {
+    NEED_CTX();
+    if (!m || !x || !local || N < 0) return gr_fail(ctx, GR_EINVAL, "gr_pg_local_logits: bad arguments");
+    const int h = net_pg_out_size(m);
+    if (h <= 0) return gr_fail(ctx, GR_EINVAL, "gr_pg_local_logits: not a PatchGuard model");
+    hipStream_t st = (hipStream_t)stream;
+    const int ncls = gr_model_num_classes(m);
+    int chunk = chunk_for(ctx, m, N);
+    if (chunk <= 0) return GR_OK;
+    int rc = gr_ws_reserve(ctx, net_workspace_bytes(m, chunk), stream);
+    if (rc) return rc;
+    for (int n0 = 0; n0 < N; n0 += chunk) {
+        int nb = N - n0 < chunk ? N - n0 : chunk;
+        if ((rc = net_pg_local(ctx, m, x + (size_t)n0 * 3072, nb, local + (size_t)n0 * h * h * ncls, ctx->ws, ctx->ws_bytes, st))) return rc;
     }
     return GR_OK;
 }
@@ -477,6 +507,7 @@ extern "C" int gr_model_input_grad(gr_ctx* ctx, gr_model* m, const float* x, int
                                    float* grad_x, void* stream) {
     NEED_CTX();
     if (!m || !x || !grad_x || N < 0) return gr_fail(ctx, GR_EINVAL, "gr_model_input_grad: bad arguments");
+    if (net_pg_out_size(m) > 0) return gr_fail(ctx, GR_EINVAL, "gr_model_input_grad: the PatchGuard classifier has no gradient path (the reference has none either)");
     hipStream_t st = (hipStream_t)stream;
     const int ncls = gr_model_num_classes(m);
     // the pass keeps every activation: ~0.8 MB per image for GTSRBNet, ~17 MB for WideResNet-34-10
@@ -540,7 +571,7 @@ extern "C" int gr_tr_hits(gr_ctx* ctx, gr_model* m, const float* img, int H, int
         if ((rc = px_warp_net(ctx, att, H, W, xf, n0, nb, have_lo, normalize, 32, net_input_x4(nws), st, in_mode, c11))) return rc;
         float* lg_out = logits ? logits + (size_t)n0 * ncls : lg;
         if ((rc = net_forward(ctx, m, nullptr, nb, lg_out, nws, net_bytes, st))) return rc;
-        if ((rc = net_hits(ctx, lg_out, nb, ncls, n0, T, target, hits, preds ? preds + n0 : nullptr, st))) return rc;
+        if ((rc = net_hits(ctx, lg_out, nb, ncls, n0, T, target, hits, preds ? preds + n0 : nullptr, st, net_tie_last(m)))) return rc;
     }
     return GR_OK;
 }

@@ -104,6 +104,14 @@ int px_warp_net(gr_ctx*, const float* att, int H, int W, const gr_xforms* xf, in
 // out + i * var_stride as [3, ny, nx] with (nx, ny) = px_net_size(crop_x, crop_y, net); clamp only, no normalisation
 void px_net_size(int crop_x, int crop_y, int net_size, int* nx, int* ny);
 
+// ---- pg.hip (PatchGuard robust classifier: pre-processing and aggregation kernels) ----
+// x: [N,3,S,S] CHW, or [N,S,S,4] when in_nhwc4.  conv1_w == nullptr: out = [N,3,D,D] CHW normalised;
+// else out = [N,D,D,64] = BagNet conv1 (1x1, 3 -> 64, weights [64][3] dev) of the normalised image.
+int pg_preprocess(gr_ctx*, const float* x, int N, int S, int D, bool in_nhwc4, const float* conv1_w, float* out, hipStream_t);
+int pg_masking(gr_ctx*, const float* local, int N, int h, int w, int ncls, int wx, int wy, float thres, float* scores,
+               int64_t* preds, hipStream_t);
+int pg_mean(gr_ctx*, const float* local, int N, int h, int w, int ncls, float* scores, hipStream_t);
+
 // ---- nets.hip ----
 struct gr_model;
 // x_chw == nullptr: the NHWC4 input (net_input_mode's layout) is already in place at net_input_x4(ws)
@@ -113,9 +121,14 @@ int net_forward(gr_ctx*, gr_model*, const float* x_chw, int N, float* logits, ch
 static inline float* net_input_x4(char* ws) { return (float*)ws; }
 int net_input_mode(const gr_model*, const float** c11);
 size_t net_workspace_bytes(const gr_model*, int N);
-int net_argmax(gr_ctx*, const float* logits, int N, int ncls, int64_t* preds, hipStream_t);
+int net_argmax(gr_ctx*, const float* logits, int N, int ncls, int64_t* preds, hipStream_t, int tie_last = 0);
+// tie_last: the LAST maximum wins (np.argsort(kind='stable')[-1], PatchGuard's masking_defense) instead of torch.max's first
 int net_hits(gr_ctx*, const float* logits, int N, int ncls, int64_t n_begin, int T, int target, int32_t* hits,
-             int64_t* preds, hipStream_t);
+             int64_t* preds, hipStream_t, int tie_last = 0);
+int net_tie_last(const gr_model*);
+// PatchGuard models: local logits [N,h,h,ncls] of N [3,32,32] inputs (x_chw == nullptr: NHWC4 input in place)
+int net_pg_local(gr_ctx*, gr_model*, const float* x_chw, int N, float* local, char* ws, size_t ws_bytes, hipStream_t);
+int net_pg_out_size(const gr_model*);
 // d CE(logits_n, target) / d x_n (GTSRBNet): forward with every activation kept, then the transposed layers
 int net_input_grad(gr_ctx*, gr_model*, const float* x_chw, int N, int target, float* logits_or_null, float* grad_x, char* ws,
                    size_t ws_bytes, hipStream_t);

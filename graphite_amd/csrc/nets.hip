@@ -36,9 +36,14 @@ struct WrnBlock {
     Layer conv1T, conv2T, scT;   // transposed (input-gradient pass): flipped taps, Cin <-> Cout, stride 1 (strided layers run on the zero-dilated gradient)
     bool has_sc;
 };
+struct BagBlock {
+    int cin, planes, k, stride;
+    Layer c1, c2, c3, ds;        // eval BatchNorm folded into each: w' = w * scale[co], bias' = shift[co]
+    bool has_ds;
+};
 struct gr_model {
     gr_ctx* ctx = nullptr;
-    int kind = 0;            // 1 = GTSRBNet, 2 = WideResNet
+    int kind = 0;            // 1 = GTSRBNet, 2 = WideResNet, 3 = PatchGuard (BagNet + masking_defense)
     int precision = GR_PREC_F32;
     int bf16_mask = 0x7f;    // layers that GR_PREC_BF16 runs in bf16: bit 0 = conv2_1 .. bit 5 = conv4_2, bit 6 = fc5 + fc6;
                              // bit 7: keep the activations between them f32 in HBM (they are bf16 when all 7 layers are)
@@ -54,6 +59,14 @@ struct gr_model {
     std::vector<WrnBlock> blocks;
     BnDev bnf;
     int ch[4] = {0, 0, 0, 0};
+    // PatchGuard (patchguard/patchguard_predict.py:21-89): bicubic up-sampling to pg_D, BagNet, robust aggregation
+    float* bag_conv1 = nullptr;  // [64][3]
+    Layer bag_conv2, bag_fc;
+    std::vector<BagBlock> bag;
+    int pg_D = 192, pg_h = 0;    // up-sampled size; side of the local-logit map
+    size_t pg_big = 0;           // floats of the largest activation per image
+    int pg_defense = 1, pg_window = 6;
+    float pg_thres = 0.f;
 };
 
 static int n_tile(int cout) {   // N tile the dispatcher will use for this many output channels
@@ -362,6 +375,94 @@ extern "C" int gr_model_load_wrn(gr_ctx* ctx, const float* const* t, const int64
     return GR_OK;
 }
 
+// ---- PatchGuard: BagNet (inspire-group/PatchGuard nets/bagnet.py = Brendel & Bethge's bagnets/pytorchnet.py; third-party
+// source absent from the reference, architecture restated -- oracle/graphite_oracle.c or_bagnet_forward has the text) ----
+// conv (no bias) followed by eval BatchNorm, folded: w' = w * scale[co] (float32), bias' = shift[co]
+static int make_layer_bn(gr_model* m, Layer* L, const float* w, const float* const* bn, int Co, int Ci, int K, int stride) {
+    std::vector<float> ws((size_t)Co * Ci * K * K), sh(Co);
+    for (int o = 0; o < Co; o++) {
+        const float invstd = 1.0f / sqrtf(bn[3][o] + 1e-5f);
+        const float sc = bn[0][o] * invstd;
+        sh[o] = bn[1][o] - bn[2][o] * sc;
+        for (size_t e = 0; e < (size_t)Ci * K * K; e++) ws[(size_t)o * Ci * K * K + e] = w[(size_t)o * Ci * K * K + e] * sc;
+    }
+    return make_layer(m, L, ws.data(), sh.data(), Co, Ci, K, K, stride, 0);
+}
+
+extern "C" int gr_model_load_bagnet(gr_ctx* ctx, const float* const* t, const int64_t* numel, int n, const int* layers,
+                                    const int* strides, const int* kernel3, int ncls, int upsample, gr_model** out) {
+    if (!ctx) return GR_EINVAL;
+    if (!t || !numel || !out || !layers || !strides || !kernel3 || ncls < 1 || ncls > 256 || upsample < 8 || upsample > 1024)
+        return gr_fail(ctx, GR_EINVAL, "gr_model_load_bagnet: bad arguments");
+    int want = 6;
+    for (int g = 0; g < 4; g++) {
+        if (layers[g] < 1 || layers[g] > 64 || strides[g] < 1 || strides[g] > 2 || kernel3[g] < 0 || kernel3[g] > 1)
+            return gr_fail(ctx, GR_EINVAL, "gr_model_load_bagnet: stage %d: layers %d, stride %d, kernel3 %d unsupported", g,
+                           layers[g], strides[g], kernel3[g]);
+        want += 15 * layers[g] + 5;
+    }
+    want += 2;
+    if (n != want) return gr_fail(ctx, GR_EINVAL, "gr_model_load_bagnet: %d tensors given, %d expected", n, want);
+    for (int i = 0; i < n; i++)
+        if (!t[i]) return gr_fail(ctx, GR_EINVAL, "null tensor %d", i);
+    GR_HIP(ctx, hipSetDevice(ctx->device));
+    gr_model* m = new gr_model();
+    m->ctx = ctx; m->kind = 3; m->ncls = ncls; m->pg_D = upsample;
+    int ti = 0, rc = expect(ctx, numel, 0, 64 * 3);
+    if (!rc) { std::vector<float> c(t[0], t[0] + 192); rc = upload(m, c, &m->bag_conv1); }
+    ti = 1;
+    if (!rc) rc = expect(ctx, numel, ti, 64 * 64 * 9);
+    for (int q = 1; q <= 4 && !rc; q++) rc = expect(ctx, numel, ti + q, 64);
+    if (!rc) rc = make_layer_bn(m, &m->bag_conv2, t[ti], t + ti + 1, 64, 64, 3, 1);
+    ti += 5;
+    int inpl = 64, H = upsample - 2;
+    size_t big = (size_t)upsample * upsample * 64;
+    for (int g = 0; g < 4 && !rc; g++)
+        for (int i = 0; i < layers[g] && !rc; i++) {
+            BagBlock b;
+            b.planes = 64 << g; b.cin = inpl; b.k = kernel3[g] > i ? 3 : 1; b.stride = i == 0 ? strides[g] : 1; b.has_ds = i == 0;
+            const int co[3] = {b.planes, b.planes, 4 * b.planes}, ci[3] = {b.cin, b.planes, b.planes}, kk[3] = {1, b.k, 1};
+            Layer* L[3] = {&b.c1, &b.c2, &b.c3};
+            for (int j = 0; j < 3 && !rc; j++) {
+                rc = expect(ctx, numel, ti, (int64_t)co[j] * ci[j] * kk[j] * kk[j]);
+                for (int q = 1; q <= 4 && !rc; q++) rc = expect(ctx, numel, ti + q, co[j]);
+                if (!rc) rc = make_layer_bn(m, L[j], t[ti], t + ti + 1, co[j], ci[j], kk[j], j == 1 ? b.stride : 1);
+                ti += 5;
+            }
+            if (b.has_ds && !rc) {
+                rc = expect(ctx, numel, ti, (int64_t)4 * b.planes * b.cin);
+                for (int q = 1; q <= 4 && !rc; q++) rc = expect(ctx, numel, ti + q, 4 * b.planes);
+                if (!rc) rc = make_layer_bn(m, &b.ds, t[ti], t + ti + 1, 4 * b.planes, b.cin, 1, b.stride);
+                ti += 5;
+            }
+            if ((size_t)H * H * b.cin > big) big = (size_t)H * H * b.cin;
+            if (H < b.k) rc = gr_fail(ctx, GR_EINVAL, "gr_model_load_bagnet: a %d x %d input is too small for this net", upsample, upsample);
+            H = (H - b.k) / b.stride + 1;
+            if ((size_t)H * H * 4 * b.planes > big) big = (size_t)H * H * 4 * b.planes;
+            inpl = 4 * b.planes;
+            m->bag.push_back(b);
+        }
+    if (!rc) rc = expect(ctx, numel, ti, (int64_t)ncls * inpl);
+    if (!rc) rc = expect(ctx, numel, ti + 1, ncls);
+    if (!rc) rc = make_layer(m, &m->bag_fc, t[ti], t[ti + 1], ncls, inpl, 1, 1, 1, 0);
+    if (!rc && H < 1) rc = gr_fail(ctx, GR_EINVAL, "gr_model_load_bagnet: empty local-logit map");
+    m->pg_h = H; m->pg_big = big;
+    m->pg_window = H < 6 ? H : 6;            // ceil((30 + 17 - 1) / 8), patchguard_predict.py:33-36
+    if (rc) { gr_model_destroy(m); return rc; }
+    *out = m;
+    return GR_OK;
+}
+
+extern "C" int gr_pg_configure(gr_model* m, int defense, int window, float thres) {
+    if (!m) return GR_EINVAL;
+    if (m->kind != 3) return gr_fail(m->ctx, GR_EINVAL, "gr_pg_configure: not a PatchGuard model");
+    if (window < 1 || window > m->pg_h) return gr_fail(m->ctx, GR_EINVAL, "gr_pg_configure: window %d outside 1..%d", window, m->pg_h);
+    m->pg_defense = defense ? 1 : 0; m->pg_window = window; m->pg_thres = thres;
+    return GR_OK;
+}
+int net_pg_out_size(const gr_model* m) { return (m && m->kind == 3) ? m->pg_h : 0; }
+extern "C" int gr_pg_out_size(const gr_model* m) { return net_pg_out_size(m); }
+
 extern "C" void gr_model_destroy(gr_model* m) {
     if (!m) return;
     for (void* p : m->allocs) (void)hipFree(p);
@@ -434,7 +535,7 @@ __global__ void k_avgpool(const float* __restrict__ in, int N, int P, int C, flo
 // torch.max(out,1): first maximum.  One lane per image; hits reduced across the wavefront when all
 // 64 lanes belong to one candidate (ballot + popcount -> one atomic), per-lane atomics otherwise.
 __global__ void k_argmax_hits(const float* __restrict__ logits, int N, int ncls, long long n_begin, int T, int target,
-                              int* __restrict__ hits, long long* __restrict__ preds) {
+                              int* __restrict__ hits, long long* __restrict__ preds, int tie_last) {
     int idx = blockIdx.x * blockDim.x + threadIdx.x;
     bool live = idx < N;
     int best = 0;
@@ -443,7 +544,7 @@ __global__ void k_argmax_hits(const float* __restrict__ logits, int N, int ncls,
         float bv = l[0];
         for (int c = 1; c < ncls; c++) {
             float v = l[c];
-            if (v > bv) { bv = v; best = c; }
+            if (tie_last ? v >= bv : v > bv) { bv = v; best = c; }
         }
         if (preds) preds[idx] = best;
     }
@@ -478,7 +579,7 @@ static bool cc_bf16_ok(const Layer& L, int H, int precision) {
 // in_bf / act_bf (bf16 kernel only): `in` holds bf16, `out_act` is written as bf16
 static int run_conv(gr_ctx* ctx, const Layer& L, const float* in, int B, int H, int W, const float* res, const BnDev* act,
                     float* out_raw, float* out_act, bool relu, bool pool, hipStream_t st, const float* gate = nullptr,
-                    int precision = GR_PREC_F32, bool in_bf = false, bool act_bf = false) {
+                    int precision = GR_PREC_F32, bool in_bf = false, bool act_bf = false, int out_hw = 0) {
     ConvParams p;
     p.in = in; p.wgt = L.w; p.bias = L.bias; p.res = res; p.gate = gate;
     p.scale = act ? act->scale : nullptr; p.shift = act ? act->shift : nullptr;
@@ -486,6 +587,10 @@ static int run_conv(gr_ctx* ctx, const Layer& L, const float* in, int B, int H, 
     p.H = H; p.W = W; p.Cin = L.Cin;
     p.Ho = (H + 2 * L.pad - L.KH) / L.stride + 1;
     p.Wo = (W + 2 * L.pad - L.KW) / L.stride + 1;
+    if (out_hw > 0) {               // only the top-left out_hw x out_hw outputs (BagNet crops the residual branch to that corner)
+        if (out_hw > p.Ho || out_hw > p.Wo) return gr_fail(ctx, GR_EINVAL, "conv: crop %d exceeds the output %dx%d", out_hw, p.Ho, p.Wo);
+        p.Ho = p.Wo = out_hw;
+    }
     p.Cout = L.Cout; p.NP = L.NP; p.KH = L.KH; p.KW = L.KW; p.stride = L.stride; p.pad = L.pad;
     long long M = (long long)B * p.Ho * p.Wo;
     if (M > 0x7fffffff - 512) return gr_fail(ctx, GR_EINVAL, "conv: M too large");
@@ -607,6 +712,7 @@ static int run_conv(gr_ctx* ctx, const Layer& L, const float* in, int B, int H, 
 // per-image workspace in floats
 static size_t per_image_floats(const gr_model* m) {
     if (m->kind == 1) return 4096 + 32768 + 8192;                  // x4 + bufA + bufB
+    if (m->kind == 3) return 4096 + 4 * m->pg_big + (size_t)m->pg_h * m->pg_h * m->ncls;   // x4 + X, T1, T2, R + local logits
     size_t big = (size_t)1024 * m->ch[1];
     if ((size_t)256 * m->ch[2] > big) big = (size_t)256 * m->ch[2];
     return 4096 + 5 * big;                                          // x4 + x, o, u, s, y
@@ -1241,6 +1347,47 @@ static int wrn_input_grad(gr_ctx* ctx, gr_model* m, const float* x, int N, int t
     return GR_OK;
 }
 
+// local logits [N,h,h,ncls] of a PatchGuard model (patchguard_predict.py:42-44): pre-processing + conv1 in one kernel, then
+// the folded conv+BN layers on the fp32 MFMA implicit-GEMM kernel (1x1 convs are plain GEMMs over N*H*W rows)
+int net_pg_local(gr_ctx* ctx, gr_model* m, const float* x, int N, float* local, char* wsb, size_t ws_bytes, hipStream_t st) {
+    if (N <= 0) return GR_OK;
+    if (m->kind != 3) return gr_fail(ctx, GR_EINVAL, "not a PatchGuard model");
+    if (ws_bytes < net_workspace_bytes(m, N)) return gr_fail(ctx, GR_ESTATE, "net_pg_local: workspace too small");
+    float* ws = (float*)wsb;
+    float* x4 = ws;
+    float* X = x4 + (size_t)N * 4096;
+    float* T1 = X + (size_t)N * m->pg_big;
+    float* T2 = T1 + (size_t)N * m->pg_big;
+    float* R = T2 + (size_t)N * m->pg_big;
+    int rc;
+    const int D = m->pg_D;
+    if ((rc = pg_preprocess(ctx, x ? x : x4, N, 32, D, x == nullptr, m->bag_conv1, T1, st))) return rc;
+    if ((rc = run_conv(ctx, m->bag_conv2, T1, N, D, D, nullptr, nullptr, X, nullptr, true, false, st))) return rc;
+    int H = D - 2;
+    for (BagBlock& b : m->bag) {
+        const int Ho = (H - b.k) / b.stride + 1;
+        if ((rc = run_conv(ctx, b.c1, X, N, H, H, nullptr, nullptr, T1, nullptr, true, false, st))) return rc;
+        if ((rc = run_conv(ctx, b.c2, T1, N, H, H, nullptr, nullptr, T2, nullptr, true, false, st))) return rc;
+        const float* res = X;
+        if (b.has_ds) {             // 1x1 stride-s conv + BN; only the Ho x Ho corner the crop keeps
+            if ((rc = run_conv(ctx, b.ds, X, N, H, H, nullptr, nullptr, R, nullptr, false, false, st, nullptr, GR_PREC_F32, false, false, Ho))) return rc;
+            res = R;
+        } else if (Ho != H) return gr_fail(ctx, GR_ESTATE, "bagnet: identity residual of a different size");
+        if ((rc = run_conv(ctx, b.c3, T2, N, Ho, Ho, res, nullptr, T1, nullptr, true, false, st))) return rc;
+        float* tmp = X; X = T1; T1 = tmp;
+        H = Ho;
+    }
+    return run_conv(ctx, m->bag_fc, X, N, H, H, nullptr, nullptr, local, nullptr, false, false, st);
+}
+
+static int pg_forward(gr_ctx* ctx, gr_model* m, const float* x, int N, float* logits, char* ws, size_t ws_bytes, hipStream_t st) {
+    float* local = (float*)ws + (size_t)N * (4096 + 4 * m->pg_big);
+    int rc = net_pg_local(ctx, m, x, N, local, ws, ws_bytes, st);
+    if (rc) return rc;
+    if (m->pg_defense) return pg_masking(ctx, local, N, m->pg_h, m->pg_h, m->ncls, m->pg_window, m->pg_window, m->pg_thres, logits, nullptr, st);
+    return pg_mean(ctx, local, N, m->pg_h, m->pg_h, m->ncls, logits, st);
+}
+
 int net_input_mode(const gr_model* m, const float** c11) {
     if (m->kind == 1) { *c11 = m->c11; return GR_OUT_NHWC4_C11; }
     *c11 = nullptr;
@@ -1252,18 +1399,20 @@ int net_forward(gr_ctx* ctx, gr_model* m, const float* x, int N, float* logits, 
     if (ws_bytes < net_workspace_bytes(m, N)) return gr_fail(ctx, GR_ESTATE, "net_forward: workspace too small");
     if (m->kind == 1) return gtsrb_forward(ctx, m, x, N, logits, (float*)ws, st);
     if (m->kind == 2) return wrn_forward(ctx, m, x, N, logits, (float*)ws, st);
+    if (m->kind == 3) return pg_forward(ctx, m, x, N, logits, ws, ws_bytes, st);
     return gr_fail(ctx, GR_ESTATE, "unknown model kind");
 }
 
 int net_hits(gr_ctx* ctx, const float* logits, int N, int ncls, int64_t n_begin, int T, int target, int32_t* hits,
-             int64_t* preds, hipStream_t st) {
+             int64_t* preds, hipStream_t st, int tie_last) {
     if (N <= 0) return GR_OK;
     ProfScope ps_(ctx, "k_argmax_hits", st, 0.0, (double)N * ncls * 4);
     hipLaunchKernelGGL(k_argmax_hits, dim3((N + 255) / 256), dim3(256), 0, st, logits, N, ncls, (long long)n_begin, T,
-                       target, (int*)hits, (long long*)preds);
+                       target, (int*)hits, (long long*)preds, tie_last);
     GR_HIP(ctx, hipGetLastError());
     return GR_OK;
 }
-int net_argmax(gr_ctx* ctx, const float* logits, int N, int ncls, int64_t* preds, hipStream_t st) {
-    return net_hits(ctx, logits, N, ncls, 0, 1, -1, nullptr, preds, st);
+int net_argmax(gr_ctx* ctx, const float* logits, int N, int ncls, int64_t* preds, hipStream_t st, int tie_last) {
+    return net_hits(ctx, logits, N, ncls, 0, 1, -1, nullptr, preds, st, tie_last);
 }
+int net_tie_last(const gr_model* m) { return (m && m->kind == 3 && m->pg_defense) ? 1 : 0; }

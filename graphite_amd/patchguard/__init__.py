@@ -4,9 +4,9 @@
   pg_generate_mask   patchguard/pg_generate_mask.py   mask generation on the baseline pg table
   pg_boost           patchguard/pg_boost.py           RGF boosting on the baseline pg table (5-tuple for CIFAR)
   main_patchguard    patchguard/main_patchguard.py    attack driver
-  patchguard_predict patchguard/patchguard_predict.py the robust classifier: NOT built (un-vendored BagNet-17 + masking_defense
-                                                      from inspire-group/PatchGuard, no weights); any object with .predict()
-                                                      takes its place
+  patchguard_predict patchguard/patchguard_predict.py the robust classifier: bicubic x6 + Normalize (reference code) as a HIP kernel,
+                                                      BagNet-17 and masking_defense (third-party, restated from the
+                                                      publications, parity unpinned) on the MFMA conv kernels / a HIP epilogue
 
 All pixel work and the batched evaluation are the same HIP path as the GTSRB / CIFAR flavours (model_type 'PATCHGUARD'
 inside graphite_amd selects normalisation and the pg parameter table).

@@ -165,6 +165,68 @@ def wrn_state_dict(tag: str = "wrn-v1", depth: int = 34, widen: int = 10, num_cl
     return sd
 
 
+# --------------------------------------------------------------------------
+# BagNet (PatchGuard's nets/bagnet.py; bagnet17 = layers [3,4,6,3], strides [2,2,2,1], kernel3 [1,1,1,0])
+# --------------------------------------------------------------------------
+BAGNET17 = dict(layers=(3, 4, 6, 3), strides=(2, 2, 2, 1), kernel3=(1, 1, 1, 0))
+
+
+def bagnet_layout(layers=(3, 4, 6, 3), num_classes: int = 10):
+    """List of (state_dict key, shape, kind) in module order (the keys of a torch BagNet's state_dict)."""
+    def bn(prefix, c):
+        return [(prefix + ".weight", (c,), "bn_w"), (prefix + ".bias", (c,), "bn_b"),
+                (prefix + ".running_mean", (c,), "bn_m"), (prefix + ".running_var", (c,), "bn_v"),
+                (prefix + ".num_batches_tracked", (), "bn_n")]
+
+    out = [("conv1.weight", (64, 3, 1, 1), "conv"), ("conv2.weight", (64, 64, 3, 3), "conv")] + bn("bn1", 64)
+    inpl = 64
+    for g, nblk in enumerate(layers):
+        planes = 64 << g
+        for i in range(nblk):
+            p = f"layer{g + 1}.{i}"
+            out += [(p + ".conv1.weight", (planes, inpl, 1, 1), "conv")] + bn(p + ".bn1", planes)
+            out += [(p + ".conv2.weight", (planes, planes, None, None), "conv_k")] + bn(p + ".bn2", planes)
+            out += [(p + ".conv3.weight", (4 * planes, planes, 1, 1), "conv")] + bn(p + ".bn3", 4 * planes)
+            if i == 0:
+                out += [(p + ".downsample.0.weight", (4 * planes, inpl, 1, 1), "conv")] + bn(p + ".downsample.1", 4 * planes)
+            inpl = 4 * planes
+    out += [("fc.weight", (num_classes, inpl), "fc_w"), ("fc.bias", (num_classes,), "fc_b")]
+    return out
+
+
+def bagnet_state_dict(tag: str = "bagnet-v1", layers=(3, 4, 6, 3), kernel3=(1, 1, 1, 0), num_classes: int = 10,
+                      calibrated: bool = True):
+    """Seeded stand-in for bagnet17_192_cifar.pth (absent, README.md:117).  He-uniform convs; the BatchNorm of every
+    block's conv3 (and downsample) is scaled so that the residual sum keeps O(1) activations through 16 blocks."""
+    sd = {}
+    for key, shape, kind in bagnet_layout(layers, num_classes):
+        name = f"{tag}/{key}"
+        if kind == "conv_k":
+            g, i = int(key[5]) - 1, int(key.split(".")[1])
+            k = 3 if kernel3[g] > i else 1
+            shape, kind = (shape[0], shape[1], k, k), "conv"
+        if kind == "conv":
+            b = float(np.sqrt(6.0 / int(np.prod(shape[1:]))))
+            sd[key] = hash_uniform(name, shape, -b, b)
+        elif kind == "bn_w":
+            lo, hi = (0.5, 0.8) if (".bn3." in key or ".downsample.1." in key) else (0.8, 1.2)
+            sd[key] = hash_uniform(name, shape, lo, hi)
+        elif kind in ("bn_b", "bn_m"):
+            sd[key] = hash_uniform(name, shape, -0.1, 0.1)
+        elif kind == "bn_v":
+            sd[key] = hash_uniform(name, shape, 0.8, 1.2)
+        elif kind == "bn_n":
+            sd[key] = np.array(1, dtype=np.int64)
+        elif kind == "fc_w":
+            b = float(np.sqrt(6.0 / shape[1]))
+            sd[key] = hash_uniform(name, shape, -b, b)
+        elif kind == "fc_b":
+            sd[key] = hash_uniform(name, shape, -0.05, 0.05)
+    if calibrated and (tuple(layers), tuple(kernel3), num_classes) == ((3, 4, 6, 3), (1, 1, 1, 0), 10):
+        sd["fc.bias"] = _calibrated_bias(tag)          # local logits centred per class (tests/golden/make_calibration.py)
+    return sd
+
+
 def state_dict_checksum(sd) -> str:
     """Order-independent 64-bit checksum of a state dict (hex)."""
     acc = 0

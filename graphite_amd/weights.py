@@ -47,3 +47,28 @@ def wrn_tensor_list(state_dict, depth=34, widen=10):
     out.append(_np(state_dict["fc.weight"]))
     out.append(_np(state_dict["fc.bias"]))
     return out
+
+
+def bagnet_tensor_list(state_dict, layers=(3, 4, 6, 3)):
+    """conv1.weight, conv2.weight, bn1 (weight, bias, running_mean, running_var); per stage and block: conv1.weight, bn1
+    (four), conv2.weight, bn2 (four), conv3.weight, bn3 (four), [downsample.0.weight, downsample.1 (four) in block 0];
+    fc.weight, fc.bias.  Keys of a DataParallel checkpoint ('module.' prefix, patchguard_predict.py:27-29) are accepted;
+    `num_batches_tracked` is skipped."""
+    sd = {(k[7:] if k.startswith("module.") else k): v for k, v in state_dict.items()}
+
+    def bn(prefix):
+        return [_np(sd[prefix + s]) for s in (".weight", ".bias", ".running_mean", ".running_var")]
+
+    out = [_np(sd["conv1.weight"]), _np(sd["conv2.weight"])] + bn("bn1")
+    for g, nblk in enumerate(layers):
+        for i in range(nblk):
+            p = f"layer{g + 1}.{i}"
+            for j in (1, 2, 3):
+                out.append(_np(sd[f"{p}.conv{j}.weight"]))
+                out += bn(f"{p}.bn{j}")
+            if i == 0:
+                out.append(_np(sd[p + ".downsample.0.weight"]))
+                out += bn(p + ".downsample.1")
+    out.append(_np(sd["fc.weight"]))
+    out.append(_np(sd["fc.bias"]))
+    return out

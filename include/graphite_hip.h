@@ -171,6 +171,40 @@ int gr_model_forward(gr_ctx* ctx, gr_model* m, const float* x, int N, float* log
 /* predict(): torch.max(logits,1) first-maximum rule (GTSRBNet.py:66) -> preds [N] int64 dev. */
 int gr_model_predict(gr_ctx* ctx, gr_model* m, const float* x, int N, int64_t* preds, void* stream);
 
+/* ---- PatchGuard robust classifier, patchguard/patchguard_predict.py:21-89 (BASELINE config 5) --------------------------
+ * forward (:38-50):  z = (x + 0.5) * 255;  z = F.interpolate(z, 192, mode='bicubic') / 255;  z = Normalize(mean, std)(z)
+ *                    local = bagnet17(aggregation='none')(z)                       [B, 22, 22, 10] local logits
+ *                    pred_i = masking_defense(local[i], thres=0.0, window_shape=[6, 6])
+ * Lines 42-44 and the Normalize of :30-32 are REFERENCE code (torch's upsample_bicubic2d, A = -0.75, half-pixel centres,
+ * clamped border taps); BagNet-17 (PatchGuard.nets.bagnet) and masking_defense (PatchGuard.utils.defense_utils) are
+ * THIRD-PARTY code of inspire-group/PatchGuard @ ae23629 (README.md:113-117) whose source and checkpoint are absent:
+ * both are restated from the publications (BagNet: Brendel & Bethge, ICLR 2019; masking: PatchGuard Algorithm 1) --
+ * "parity unpinned" for those two.
+ *
+ * gr_pg_preprocess (:42-44, :30-32): x [N,3,S,S] dev in [-0.5,0.5] -> out [N,3,D,D] dev, normalised. */
+int gr_pg_preprocess(gr_ctx* ctx, const float* x, int N, int S, int D, float* out, void* stream);
+/* BagNet (:24-29).  tensors (host, PyTorch layouts): conv1.weight [64,3,1,1], conv2.weight [64,64,3,3], bn1.{weight, bias,
+ * running_mean, running_var}; per stage g = 0..3 (planes 64 << g) and block i < layers[g]: conv1.weight, bn1.{4},
+ * conv2.weight (k x k, k = 3 iff kernel3[g] > i, stride strides[g] in block 0), bn2.{4}, conv3.weight, bn3.{4},
+ * [downsample.0.weight, downsample.1.{4} in block 0]; fc.weight [ncls, 2048], fc.bias.  bagnet17: layers {3,4,6,3},
+ * strides {2,2,2,1}, kernel3 {1,1,1,0}.  `upsample` = the bicubic target size (192, :43).  The model's input is
+ * [N,3,32,32] in [-0.5,0.5] as for the other classifiers; gr_model_forward returns [N,ncls] = the masked class evidence
+ * (defense on, the default) or the mean local logits (PatchGuardNoDefense, :56-89), gr_model_predict / gr_tr_hits take
+ * the LAST maximum with the defense on (np.argsort(kind='stable')[-1]) and the first otherwise (np.argmax). */
+int gr_model_load_bagnet(gr_ctx* ctx, const float* const* tensors, const int64_t* numel, int n, const int* layers,
+                         const int* strides, const int* kernel3, int num_classes, int upsample, gr_model** out);
+/* defense != 0: masking_defense with this window (default 6 = ceil((30 + 17 - 1) / 8), :33-36) and threshold (0.0, :48);
+ * defense == 0: mean aggregation. */
+int gr_pg_configure(gr_model* m, int defense, int window, float thres);
+/* side h of the local-logit map (22 for bagnet17 at 192); 0 for other models */
+int gr_pg_out_size(const gr_model* m);
+/* local logits (:44): x [N,3,32,32] dev -> local [N,h,h,ncls] dev */
+int gr_pg_local_logits(gr_ctx* ctx, gr_model* m, const float* x, int N, float* local, void* stream);
+/* masking_defense (:48) on caller-supplied local logits [N,h,w,ncls] dev (any local-logit net can sit in front):
+ * scores [N,ncls] dev = masked class evidence, preds [N] int64 dev; either may be NULL.  h*w*ncls*4 <= 64 KB. */
+int gr_pg_masking_defense(gr_ctx* ctx, const float* local, int N, int h, int w, int ncls, int window, float thres,
+                          float* scores, int64_t* preds, void* stream);
+
 /* Input gradient of the classifier for the whitebox EOT loop (whitebox_attack.py:155-158:
  * logits = model(x); loss = CrossEntropyLoss(logits, target); grad = autograd.grad(loss, x)):
  * grad_x [N,3,32,32] dev = d CE(logits_n, target) / d x_n PER IMAGE (no averaging over N); logits [N,ncls] dev optional.

@@ -419,7 +419,7 @@ static float* repack_oihw(const float* w, int Co, int Ci, int KH, int KW) {
  * leaves the order to cuDNN; either order is within 2e-6 relative of its PyTorch forward (tests/golden/nets.npz). */
 static void conv_nhwc(const float* in, int H, int W, int Ci, const float* wp, int KH, int KW, int stride, int pad,
                       float* out, int Ho, int Wo, int Co) {
-    float acc[1024];
+    float acc[4096];
     const int cc = (KH == 3 && KW == 3 && stride == 1 && Ci % 32 == 0) ? 32 : Ci;
     for (int oy = 0; oy < Ho; oy++)
         for (int ox = 0; ox < Wo; ox++) {

@@ -4,7 +4,8 @@
 Random-init nets predict one constant class for every input, which would make
 every hit-count comparison trivially true.  This script runs the CPU oracle on
 a calibration set (config-1 style warped stop-sign composites for GTSRBNet,
-config-3 style synthetic 32x32 composites for WRN-34-10), and stores
+config-3 style synthetic 32x32 composites for WRN-34-10, config-5 style composites through the PatchGuard pre-processing
+for BagNet-17, whose LOCAL logits are centred per class over images and positions), and stores
 `bias - mean(logits)` so that the arg-max depends on the input.  Output:
 graphite_amd/data/<tag>_last_bias.npy (exact float32), loaded by graphite_amd.synth.
 
@@ -24,7 +25,7 @@ import oracle_lib as O                                   # noqa: E402
 from graphite_amd import synth, transforms as T, weights  # noqa: E402
 from graphite_amd.imageio import load_image_chw           # noqa: E402
 
-INP = os.path.join(HERE, "inputs")
+INP = os.path.join(REPO, "graphite_amd", "data", "inputs")
 OUT = os.path.join(REPO, "graphite_amd", "data")
 
 
@@ -66,6 +67,26 @@ def wrn():
     print("wrn: class histogram on the calibration set:", np.bincount(p, minlength=10))
 
 
+def bagnet():
+    vic = synth.synth_victim("cifar-calib", 32)
+    tar = synth.synth_victim("cifar-calib-target", 32)
+    ones = np.ones((3, 32, 32), np.float32)
+    np.random.seed(42)
+    tab = T.build_xform_table(T.get_transform_params(12, "CIFAR", baseline=True, patchguard=True), 32, 32, None)
+    masks = np.concatenate([ones[None], synth.synth_patch_masks("calib-pg", 3, ones)])
+    thetas = (tar - vic)[None] * masks
+    imgs = O.warp_batch(vic, masks, thetas, tab, normalize=True).reshape(-1, 3, 32, 32)
+    sd = synth.bagnet_state_dict("bagnet-v1", calibrated=False)
+    lo = O.bagnet_forward(weights.bagnet_tensor_list(sd), O.pg_preprocess(imgs))
+    bias = (sd["fc.bias"].astype(np.float64) - lo.astype(np.float64).mean((0, 1, 2))).astype(np.float32)
+    np.save(os.path.join(OUT, "bagnet-v1_last_bias.npy"), bias)
+    sd["fc.bias"] = bias
+    lo = O.bagnet_forward(weights.bagnet_tensor_list(sd), O.pg_preprocess(imgs))
+    print("bagnet17: robust (masking_defense) class histogram on the calibration set:",
+          np.bincount(O.masking_defense(lo)[1], minlength=10), "undefended:", np.bincount(O.pg_mean_logits(lo).argmax(1), minlength=10))
+
+
 if __name__ == "__main__":
-    gtsrb()
-    wrn()
+    which = sys.argv[1:] or ["gtsrb", "wrn", "bagnet"]
+    for name in which:
+        {"gtsrb": gtsrb, "wrn": wrn, "bagnet": bagnet}[name]()

@@ -172,3 +172,50 @@ def argmax_hits(logits, T, target):
     _check(lib().or_argmax_hits(pl, N, ncls, T, int(target), preds.ctypes.data_as(C.c_void_p),
                                 hits.ctypes.data_as(C.c_void_p)), "argmax_hits")
     return preds, hits
+
+
+# ---- PatchGuard robust classifier (patchguard/patchguard_predict.py:21-53) ----
+def pg_preprocess(x, size=192, nthreads=8):
+    x, px = _f(x)
+    N, _, S, _ = x.shape
+    out = np.empty((N, 3, size, size), np.float32)
+    _check(lib().or_pg_preprocess(px, N, S, size, out.ctypes.data_as(C.c_void_p), nthreads), "pg_preprocess")
+    return out
+
+
+def _i4(v):
+    return (C.c_int * 4)(*[int(a) for a in v])
+
+
+def bagnet_out_size(D, layers, strides, kernel3):
+    return int(lib().or_bagnet_out_size(int(D), _i4(layers), _i4(strides), _i4(kernel3)))
+
+
+def bagnet_forward(tensors, z, layers=(3, 4, 6, 3), strides=(2, 2, 2, 1), kernel3=(1, 1, 1, 0), num_classes=10, nthreads=8):
+    """z [N,3,D,D] (normalised) -> local logits [N,h,h,num_classes]."""
+    keep, arr = _tensor_array(tensors)
+    z, pz = _f(z)
+    N, _, D, _ = z.shape
+    h = bagnet_out_size(D, layers, strides, kernel3)
+    local = np.empty((N, h, h, num_classes), np.float32)
+    _check(lib().or_bagnet_forward(arr, len(keep), _i4(layers), _i4(strides), _i4(kernel3), num_classes, pz, N, D,
+                                   local.ctypes.data_as(C.c_void_p), nthreads), "bagnet_forward")
+    return local
+
+
+def masking_defense(local, window=6, thres=0.0):
+    local, pl = _f(local)
+    N, h, w, ncls = local.shape
+    scores = np.empty((N, ncls), np.float32)
+    preds = np.empty(N, np.int64)
+    _check(lib().or_masking_defense(pl, N, h, w, ncls, window, window, C.c_float(thres), scores.ctypes.data_as(C.c_void_p),
+                                    preds.ctypes.data_as(C.c_void_p)), "masking_defense")
+    return scores, preds
+
+
+def pg_mean_logits(local):
+    local, pl = _f(local)
+    N, h, w, ncls = local.shape
+    scores = np.empty((N, ncls), np.float32)
+    _check(lib().or_pg_mean_logits(pl, N, h, w, ncls, scores.ctypes.data_as(C.c_void_p)), "pg_mean_logits")
+    return scores
