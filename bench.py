@@ -117,13 +117,41 @@ def extras(_hip, engine, models, synth):
                 "bf16_conv_frac_of_bf16_mfma_peak": sum(v["flops"] for v in p16.values()) / (sum(v["ms"] for v in p16.values()) * 1e-3) / 1e12 / PEAK_BF16_MFMA,
                 "max_abs_hit_count_diff_vs_f32_of_100": int((h16 - h).abs().max().item())}
     del wrn
-    # ---- config 5: PatchGuard parameter table (pg_transforms.py:67-94, baseline=True); the BagNet robust classifier is
-    # un-vendored third-party code with no weights here, so only the warp stage is timed
+    # ---- config 5: PatchGuard variant (pg_transforms.py:67-94 table with baseline=True -> warp -> patchguard_predict.py:
+    # bicubic x6 + Normalize, BagNet-17, masking_defense).  BagNet-17 / masking_defense are third-party code restated from
+    # the publications and the checkpoint is absent (seeded weights): throughput is real, labels are synthetic.
+    from graphite_amd.patchguard.patchguard_predict import PatchGuard
     pg = cifar_case(num_xforms=100, patchguard=True, baseline=True)
-    C5 = 512
+    pgm = PatchGuard(synth.bagnet_state_dict())
+    C5 = 32
     masks = np.concatenate([pg["hull"][None], synth.synth_patch_masks("bench-pg", C5 - 1, pg["hull"])])
     thetas = ((pg["tar_s"] - pg["vic_s"])[None] * masks).astype(np.float32)
     i5, m5, t5 = _hip.to_dev(pg["vic"]), _hip.to_dev(masks), _hip.to_dev(thetas)
+    x5 = _hip.xform_table(pg["tab"])
+    engine.tr_hits(pgm, i5, m5[:2], t5[:2], x5, 3, pt_file=None, model_type='PATCHGUARD')
+    torch.cuda.synchronize()
+    _hip.profile_reset(); _hip.profile_enable(True)
+    t0 = time.perf_counter()
+    h5 = engine.tr_hits(pgm, i5, m5, t5, x5, 3, pt_file=None, model_type='PATCHGUARD')
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    _hip.profile_enable(False)
+    p5 = _hip.profile_read()
+    cms = sum(v["ms"] for k, v in p5.items() if k.startswith("k_conv"))
+    cfl = sum(v["flops"] for k, v in p5.items() if k.startswith("k_conv"))
+    res["config5_patchguard"] = {
+        "images_per_s": C5 * 100 / dt, "ms_per_launch": 1e3 * dt, "tr_queries_per_s": C5 / dt, "candidates": C5, "transforms": 100,
+        "classifier": "PatchGuard: bicubic x6 + Normalize (reference code), BagNet-17 and masking_defense restated from the "
+                      "publications (third-party source and checkpoint absent: seeded weights, parity unpinned)",
+        "flops_per_image": cfl / (C5 * 100), "conv_tflops": cfl / (cms * 1e-3) / 1e12 if cms else None,
+        "conv_frac_of_f32_mfma_peak": cfl / (cms * 1e-3) / 1e12 / PEAK_F32_MFMA if cms else None,
+        "kernel_ms": {k: round(v["ms"], 3) for k, v in sorted(p5.items(), key=lambda kv: -kv[1]["ms"])[:8]},
+        "hits_checksum": int(h5.sum().item())}
+    # the warp stage of the same table alone (what round 2 reported for this config)
+    C5w = 512
+    masks = np.concatenate([pg["hull"][None], synth.synth_patch_masks("bench-pg", C5w - 1, pg["hull"])])
+    thetas = ((pg["tar_s"] - pg["vic_s"])[None] * masks).astype(np.float32)
+    m5, t5 = _hip.to_dev(masks), _hip.to_dev(thetas)
     _hip.warp_batch_dev(i5, m5, t5, pg["tab"], 1.0, True)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -131,10 +159,10 @@ def extras(_hip, engine, models, synth):
         o5 = _hip.warp_batch_dev(i5, m5, t5, pg["tab"], 1.0, True)
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / 5
-    res["config5_patchguard_table_warp_only"] = {
-        "images_per_s": C5 * 100 / dt, "ms_per_launch": 1e3 * dt, "candidates": C5, "transforms": 100,
-        "output_gb_per_s": C5 * 100 * 12288 / dt / 1e9, "checksum": float(o5.double().sum().item())}
-    del o5
+    res["config5_patchguard"]["warp_stage_alone"] = {
+        "images_per_s": C5w * 100 / dt, "ms_per_launch": 1e3 * dt, "candidates": C5w, "transforms": 100,
+        "output_gb_per_s": C5w * 100 * 12288 / dt / 1e9, "checksum": float(o5.double().sum().item())}
+    del o5, pgm
     # ---- whitebox EOT gradient: forward + backward of transform_wb for 100 transforms of the stop sign,
     # the inner body of whitebox_attack.py:149-162 without the classifier; checked against the torch restatement
     sys.path.insert(0, os.path.join(ROOT, "oracle"))

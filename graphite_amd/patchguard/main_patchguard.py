@@ -1,7 +1,8 @@
 """Drop-in for the reference's `patchguard/main_patchguard.py`: `attack_network` (:19-105) with the same positional
 arguments.  Paths in, PNGs out (under `out_path`, default the reference's 'outputs_reproduce/'); returns the dict
-graphite_amd.main.attack_network returns.  `attack_CIFAR` (:108-119) builds the PatchGuard classifier, which is not
-available (patchguard_predict.py) -- pass a model to `attack_network`."""
+graphite_amd.main.attack_network returns.  `attack_CIFAR` (:108-119) builds the PatchGuard classifier from the checkpoint
+path the reference hard-codes (patchguard_predict.py:28); that file is a download (README.md:117), so without it pass a
+model (e.g. PatchGuard(synth.bagnet_state_dict())) to `attack_network`."""
 from .. import main as _M
 from .. import parsearguments
 
@@ -20,6 +21,11 @@ def attack_network(model, img_v, img_t, mask, lbl_v, lbl_t, pt_file, scorefile, 
                              joint_iters=1, args=pg_args, write_outputs=write_outputs, _evaluator=_evaluator)
 
 
-def attack_CIFAR(*a, **k):
+def attack_CIFAR(*a, checkpoint='PatchGuard/checkpoints/bagnet17_192_cifar.pth', **k):
+    import os
+    import torch
     from .patchguard_predict import PatchGuard
-    return attack_network(PatchGuard(), *a, **k)
+    if not os.path.exists(checkpoint):
+        raise FileNotFoundError(checkpoint + ": the BagNet-17 checkpoint of inspire-group/PatchGuard is a separate download "
+                                "(reference README.md:117); pass a model to attack_network instead")
+    return attack_network(PatchGuard(torch.load(checkpoint, map_location='cpu', weights_only=True)), *a, **k)

@@ -57,8 +57,8 @@ class PatchGuard:
 
     @property
     def hip_model(self):
-        if self._model is None:
-            raise RuntimeError("PatchGuard: no BagNet weights loaded (load_state_dict) -- with a duck-typed `net` only "
+        if self._model is None:             # AttributeError: hasattr(model, "hip_model") is how the evaluator asks for the fused path
+            raise AttributeError("PatchGuard: no BagNet weights loaded (load_state_dict) -- with a duck-typed `net` only "
                                "predict()/forward() are available, not the fused tr_hits path")
         return self._model
 

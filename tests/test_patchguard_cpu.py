@@ -96,6 +96,7 @@ def test_whole_patchguard_prediction_of_the_two_restatements(oracle):
 def test_host_class_needs_weights_and_never_falls_back():
     from graphite_amd.patchguard.patchguard_predict import PatchGuard, PatchGuardNoDefense, WINDOW_SIZE
     assert WINDOW_SIZE == 6
-    with pytest.raises(RuntimeError):
+    with pytest.raises(AttributeError):
         PatchGuard().hip_model
+    assert not hasattr(PatchGuard(net=lambda z: z), "hip_model")      # a duck-typed middle never takes the fused path
     assert PatchGuardNoDefense._defense is False
