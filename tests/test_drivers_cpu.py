@@ -258,5 +258,5 @@ def test_pg_transforms_interface():
     with pytest.raises(AssertionError):
         P.get_transform_params(1, model_type='GTSRB')
     assert patchguard_predict.WINDOW_SIZE == 6
-    with pytest.raises(RuntimeError, match="BagNet"):
-        patchguard_predict.PatchGuard()
+    with pytest.raises(AttributeError, match="BagNet"):      # no weights, no fused path -- and no fallback
+        patchguard_predict.PatchGuard().hip_model
