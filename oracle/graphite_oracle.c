@@ -533,13 +533,16 @@ static bn_t bn_fold(const float* w, const float* b, const float* m, const float*
     }
     return r;
 }
-static void bn_relu(const float* in, size_t npix, const bn_t* bn, float* out) {
+/* mask (optional): 1 where the unit is active (v > 0), NHWC order -- the ReLU DECISIONS of this forward pass */
+static void bn_relu_m(const float* in, size_t npix, const bn_t* bn, float* out, uint8_t* mask) {
     for (size_t p = 0; p < npix; p++)
         for (int c = 0; c < bn->C; c++) {
             float v = fmaf(in[p * bn->C + c], bn->scale[c], bn->shift[c]);
             out[p * bn->C + c] = v > 0.f ? v : 0.f;
+            if (mask) mask[p * bn->C + c] = v > 0.f ? 1 : 0;
         }
 }
+static void bn_relu(const float* in, size_t npix, const bn_t* bn, float* out) { bn_relu_m(in, npix, bn, out, NULL); }
 
 typedef struct {
     int cin, cout, stride;
@@ -547,9 +550,37 @@ typedef struct {
     float *w1, *w2, *wsc;
 } wrn_block_t;
 
+/* bytes of ReLU decisions per image that or_wrn_forward_masks writes: per block relu(bn1(x)) [H,H,cin] then relu(bn2(conv1))
+ * [Ho,Ho,cout], then the final relu(bn1) [8,8,ch3]; each NHWC, one byte per unit */
+long long or_wrn_mask_bytes(int depth, int widen) {
+    if ((depth - 4) % 6 != 0) return -1;
+    int n = (depth - 4) / 6, ch[4] = {16, 16 * widen, 32 * widen, 64 * widen}, H = 32;
+    long long tot = 0;
+    for (int g = 0; g < 3; g++)
+        for (int i = 0; i < n; i++) {
+            int cin = i == 0 ? ch[g] : ch[g + 1], stride = (i == 0 && g > 0) ? 2 : 1, Ho = H / stride;
+            tot += (long long)H * H * cin + (long long)Ho * Ho * ch[g + 1];
+            H = Ho;
+        }
+    return tot + (long long)H * H * ch[3];
+}
+
+static int wrn_forward_impl(const float* const* t, int nt, int depth, int widen, int ncls, const float* x, int N,
+                            float* logits, int nthreads, uint8_t* masks);
 int or_wrn_forward(const float* const* t, int nt, int depth, int widen, int ncls, const float* x, int N,
                    float* logits, int nthreads) {
+    return wrn_forward_impl(t, nt, depth, widen, ncls, x, N, logits, nthreads, NULL);
+}
+/* the same forward, also writing every ReLU decision (or_wrn_mask_bytes per image): the HIP library's forward is this
+ * forward bit for bit, so these are ITS decisions -- what a gradient reference has to share to be compared tightly */
+int or_wrn_forward_masks(const float* const* t, int nt, int depth, int widen, int ncls, const float* x, int N,
+                         float* logits, int nthreads, uint8_t* masks) {
+    return wrn_forward_impl(t, nt, depth, widen, ncls, x, N, logits, nthreads, masks);
+}
+static int wrn_forward_impl(const float* const* t, int nt, int depth, int widen, int ncls, const float* x, int N,
+                            float* logits, int nthreads, uint8_t* masks) {
     if (!t || !x || !logits || (depth - 4) % 6 != 0) return -1;
+    const long long mbytes = or_wrn_mask_bytes(depth, widen);
     int n = (depth - 4) / 6;
     int ch[4] = {16, 16 * widen, 32 * widen, 64 * widen};
     if (ch[3] > 1024) return -2;
@@ -589,13 +620,16 @@ int or_wrn_forward(const float* const* t, int nt, int depth, int widen, int ncls
             for (int p = 0; p < 1024; p++)
                 for (int c = 0; c < 3; c++) o[p * 3 + c] = xi[c * 1024 + p];
             int H = 32;
+            uint8_t* mk = masks ? masks + (size_t)im * mbytes : NULL;
             conv_nhwc(o, 32, 32, 3, wconv1, 3, 3, 1, 1, xa, 32, 32, 16);                  /* wideresnet.py:87 */
             for (int bi = 0; bi < nb; bi++) {
                 wrn_block_t* b = &blk[bi];
                 int Ho = H / b->stride;
-                bn_relu(xa, (size_t)H * H, &b->bn1, o);                                     /* :27/:29 */
+                bn_relu_m(xa, (size_t)H * H, &b->bn1, o, mk);                               /* :27/:29 */
+                if (mk) mk += (size_t)H * H * b->cin;
                 conv_nhwc(o, H, H, b->cin, b->w1, 3, 3, b->stride, 1, u, Ho, Ho, b->cout);  /* :30 */
-                bn_relu(u, (size_t)Ho * Ho, &b->bn2, u);
+                bn_relu_m(u, (size_t)Ho * Ho, &b->bn2, u, mk);
+                if (mk) mk += (size_t)Ho * Ho * b->cout;
                 conv_nhwc(u, Ho, Ho, b->cout, b->w2, 3, 3, 1, 1, v, Ho, Ho, b->cout);       /* :33 */
                 const float* sc = xa;
                 if (b->wsc) { conv_nhwc(o, H, H, b->cin, b->wsc, 1, 1, b->stride, 0, s, Ho, Ho, b->cout); sc = s; }
@@ -603,7 +637,7 @@ int or_wrn_forward(const float* const* t, int nt, int depth, int widen, int ncls
                 for (size_t e = 0; e < ne; e++) xa[e] = sc[e] + v[e];                       /* :34 */
                 H = Ho;
             }
-            bn_relu(xa, (size_t)H * H, &bnf, o);                                            /* :91 */
+            bn_relu_m(xa, (size_t)H * H, &bnf, o, mk);                                      /* :91 */
             int C = ch[3];
             for (int c = 0; c < C; c++) {                                                   /* :92 avg_pool2d(8) */
                 float sum = 0.f;

@@ -73,6 +73,13 @@ int or_gtsrb_forward(const float* const* tensors, const float* x, int N, float* 
 int or_wrn_forward(const float* const* tensors, int ntensors, int depth, int widen, int num_classes,
                    const float* x, int N, float* logits, int nthreads);
 
+/* The same forward, also writing every ReLU decision (1 = active; or_wrn_mask_bytes(depth, widen) bytes per image: per block
+ * relu(bn1(x)) [H,H,cin] then relu(bn2(conv1)) [Ho,Ho,cout], last the final relu(bn1) [8,8,ch3], all NHWC).  The HIP
+ * library's forward is this forward bit for bit, so these are its decisions (tests/test_gpu_wb.py: gradient evidence). */
+long long or_wrn_mask_bytes(int depth, int widen);
+int or_wrn_forward_masks(const float* const* tensors, int ntensors, int depth, int widen, int num_classes,
+                         const float* x, int N, float* logits, int nthreads, uint8_t* masks);
+
 /* torch.max(out,1) first-max argmax; hits[c] += (pred == target) over the T images of candidate c. */
 int or_argmax_hits(const float* logits, int N, int ncls, int T, int target, int64_t* preds, int32_t* hits);
 

@@ -50,3 +50,24 @@ run()
 S.score_fn = _sf
 print("fine reduction outcomes (%d evaluated):" % len(seq))
 print("".join(seq))
+
+# ---- three-way split of the wall clock: device / discarded speculation / host ----
+from graphite_amd import _hip
+log = []
+E.TREvaluator.errors = _timed
+_hip.profile_reset(); _hip.profile_enable(True)
+t0 = time.perf_counter(); r = run(); torch.cuda.synchronize(); wall = time.perf_counter() - t0
+_hip.profile_enable(False)
+E.TREvaluator.errors = _orig
+prof = _hip.profile_read()
+kern = sum(v["ms"] for v in prof.values()) * 1e-3
+inside = sum(d for _, d in log)
+issued = int(r.get("queries_issued", r["queries"]))
+need = int(r["queries"])
+print("three-way split of %.3f s (profiling events on):" % wall)
+print("  device kernels            %.3f s  (%d images issued; %.3f s of it for the %d discarded speculative images at the average rate)"
+      % (kern, issued, kern * (issued - need) / issued, issued - need))
+print("  evaluator calls, not kernel %.3f s  (%d calls: H2D of masks / thetas, launch gaps, the D2H sync of the hit counts)" % (inside - kern, len(log)))
+print("  host outside the evaluator  %.3f s  (PNG / CSV decode, mask algebra, score_fn, RNG, driver control flow)" % (wall - inside))
+for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["ms"])[:12]:
+    print("    %-44s %5d launches %8.2f ms" % (k, v["launches"], v["ms"]))

@@ -164,6 +164,20 @@ def wrn_forward(tensors, depth, widen, num_classes, x, nthreads=8):
     return logits
 
 
+def wrn_forward_masks(tensors, depth, widen, num_classes, x, nthreads=8):
+    """(logits, masks uint8 [N, or_wrn_mask_bytes]) -- every ReLU decision of the forward pass."""
+    keep, arr = _tensor_array(tensors)
+    x, px = _f(x)
+    N = x.shape[0]
+    lib().or_wrn_mask_bytes.restype = C.c_longlong
+    nbytes = int(lib().or_wrn_mask_bytes(depth, widen))
+    logits = np.empty((N, num_classes), np.float32)
+    masks = np.empty((N, nbytes), np.uint8)
+    _check(lib().or_wrn_forward_masks(arr, len(keep), depth, widen, num_classes, px, N, logits.ctypes.data_as(C.c_void_p),
+                                      nthreads, masks.ctypes.data_as(C.c_void_p)), "wrn_forward_masks")
+    return logits, masks
+
+
 def argmax_hits(logits, T, target):
     logits, pl = _f(logits)
     N, ncls = logits.shape
