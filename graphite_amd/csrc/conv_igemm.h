@@ -19,6 +19,8 @@
 //   "activated" store relu(v*scale+shift) (folded eval BatchNorm of the NEXT layer, WideResNet).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdlib.h>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -37,6 +39,10 @@ struct ConvParams {
     int relu;
     const float* gate;    // [M,Cout] or null: the output is zeroed where gate <= 0 (ReLU backward of the producer's activation)
     int kchunk;           // 0: k = (ky,kx,ci).  BK: k = (ci/BK, ky, kx, ci%BK) -- the order conv_halo_cc.h walks
+    int vec_epi;          // 1: Cout % 4 == 0 and every output / residual / gate pointer is 16-byte aligned: tiles leave through
+                          //    a wave-private LDS patch as 16-byte stores (set by the launcher)
+    int raster;           // 1: 1-D grid, XCD-aware tile order (below); 0: grid (M blocks, N blocks)
+    int mblocks, nblocks;
 };
 
 template <int BK, int WM, int WN, int TM, int TN, bool POOL>
@@ -60,8 +66,20 @@ __global__ __launch_bounds__(WM* WN * 64) void k_conv_igemm(ConvParams p) {
     const int wave = tid >> 6, lane = tid & 63;
     const int wm = wave / WN, wn = wave % WN;
     const int lp = lane & 31, lh = lane >> 5;
-    const int m0 = blockIdx.x * BM;
-    const int n0 = blockIdx.y * BN;
+    // Tile order.  Workgroup i runs on XCD i % 8 (round-robin dispatch), and each XCD has its own 4 MB L2.  With the plain
+    // 2-D grid the N blocks of one M block are thousands of workgroups apart, so its A rows (BM x K floats, 1 MB for fc5)
+    // come from HBM once per N block.  Raster order: XCD x takes the M blocks m = x (mod 8) and walks ALL N blocks of an
+    // M block back to back -- A is fetched from HBM once and re-read from that XCD's L2; the weights are shared by every
+    // workgroup anyway.
+    int mb, nb;
+    if (p.raster) {
+        const int id = blockIdx.x, xcd = id & 7, j = id >> 3;
+        nb = j % p.nblocks;
+        mb = (j / p.nblocks) * 8 + xcd;
+        if (mb >= p.mblocks) return;             // padding workgroups of the last group of 8 M blocks (uniform exit, before any barrier)
+    } else { mb = blockIdx.x; nb = blockIdx.y; }
+    const int m0 = mb * BM;
+    const int n0 = nb * BN;
     const int K = p.KH * p.KW * p.Cin;
     const int nchunk = K / BK;
 
@@ -194,6 +212,68 @@ __global__ __launch_bounds__(WM* WN * 64) void k_conv_igemm(ConvParams p) {
     }
 
     // ---- epilogue: lane holds column co = .. + lp, rows (r&3) + 8*(r>>2) + 4*lh of each tile ----
+    if (!POOL && p.vec_epi) {
+        // A lane's 16 values of a tile are 16 different ROWS of one column: stored directly they leave as 4-byte scalars,
+        // 128 contiguous bytes per row and instruction (16 TFLOP/s on BagNet's K = 64 -> N = 256 expansions, which are
+        // all epilogue).  Each wave transposes its 32x32 tile through a private LDS patch (the A / B buffers are free
+        // after the last barrier; 36-float rows: conflict-free writes, 16-byte aligned reads; LDS is in order within a
+        // wave, so no barrier) and every lane then owns 4 consecutive columns of 4 rows: float4 loads of the residual /
+        // gate, float4 stores.  The arithmetic per element is unchanged: (acc + bias) + res, ReLU, gate, fma(scale, shift).
+        float* patch = smem + wave * (32 * 36);
+        const int prow = lane >> 3, pc4 = (lane & 7) * 4;
+#pragma unroll
+        for (int j = 0; j < TN; j++) {
+            const int cb = n0 + (wn * TN + j) * 32;
+            const float bias = (p.bias && cb + lp < p.Cout) ? p.bias[cb + lp] : 0.f;
+            const int co = cb + pc4;
+            const bool cok = co < p.Cout;
+            float4 sc4 = make_float4(0.f, 0.f, 0.f, 0.f), sh4 = sc4;
+            if (p.out_act && cok) {
+                sc4 = *reinterpret_cast<const float4*>(p.scale + co);
+                sh4 = *reinterpret_cast<const float4*>(p.shift + co);
+            }
+#pragma unroll
+            for (int i = 0; i < TM; i++) {
+                const int mt = m0 + (wm * TM + i) * 32;
+#pragma unroll
+                for (int r = 0; r < 16; r++) patch[((r & 3) + 8 * (r >> 2) + 4 * lh) * 36 + lp] = acc[i][j][r] + bias;
+#pragma unroll
+                for (int it = 0; it < 4; it++) {
+                    const int row = prow + 8 * it;
+                    float4 v = *reinterpret_cast<const float4*>(patch + row * 36 + pc4);
+                    const int m = mt + row;
+                    if (cok && m < p.M) {
+                        const size_t o = (size_t)m * p.Cout + co;
+                        if (p.res) {
+                            const float4 q = *reinterpret_cast<const float4*>(p.res + o);
+                            v.x = v.x + q.x; v.y = v.y + q.y; v.z = v.z + q.z; v.w = v.w + q.w;
+                        }
+                        if (p.relu) {
+                            v.x = v.x > 0.f ? v.x : 0.f; v.y = v.y > 0.f ? v.y : 0.f;
+                            v.z = v.z > 0.f ? v.z : 0.f; v.w = v.w > 0.f ? v.w : 0.f;
+                        }
+                        if (p.gate) {
+                            const float4 g = *reinterpret_cast<const float4*>(p.gate + o);
+                            if (!(g.x > 0.f)) v.x = 0.f;
+                            if (!(g.y > 0.f)) v.y = 0.f;
+                            if (!(g.z > 0.f)) v.z = 0.f;
+                            if (!(g.w > 0.f)) v.w = 0.f;
+                        }
+                        if (p.out_raw) *reinterpret_cast<float4*>(p.out_raw + o) = v;
+                        if (p.out_act) {
+                            float4 w;
+                            w.x = fmaf(v.x, sc4.x, sh4.x); w.y = fmaf(v.y, sc4.y, sh4.y);
+                            w.z = fmaf(v.z, sc4.z, sh4.z); w.w = fmaf(v.w, sc4.w, sh4.w);
+                            w.x = w.x > 0.f ? w.x : 0.f; w.y = w.y > 0.f ? w.y : 0.f;
+                            w.z = w.z > 0.f ? w.z : 0.f; w.w = w.w > 0.f ? w.w : 0.f;
+                            *reinterpret_cast<float4*>(p.out_act + o) = w;
+                        }
+                    }
+                }
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int j = 0; j < TN; j++) {
         const int co = n0 + (wn * TN + j) * 32 + lp;
@@ -255,7 +335,20 @@ static inline hipError_t launch_conv_igemm(const ConvParams& p, hipStream_t st) 
         if (e != hipSuccess) return e;
         attr_set[dev_] = true;
     }
-    dim3 grid((p.M + BM - 1) / BM, p.NP / BN);
-    hipLaunchKernelGGL(kern, grid, dim3(WM * WN * 64), smem, st, p);
+    ConvParams q = p;
+    q.mblocks = (p.M + BM - 1) / BM;
+    q.nblocks = p.NP / BN;
+    static int raster = -1;                      // GRAPHITE_IGEMM_RASTER=0: the plain 2-D grid (A/B runs)
+    if (raster < 0) { const char* e = getenv("GRAPHITE_IGEMM_RASTER"); raster = (e && e[0] == '0') ? 0 : 1; }
+    auto a16 = [](const void* ptr) { return ((uintptr_t)ptr & 15) == 0; };
+    static int vec = -1;                         // GRAPHITE_IGEMM_VEC=0: the scalar epilogue (A/B runs)
+    if (vec < 0) { const char* e = getenv("GRAPHITE_IGEMM_VEC"); vec = (e && e[0] == '0') ? 0 : 1; }
+    q.vec_epi = (vec && !POOL && p.Cout % 4 == 0 && a16(p.out_raw) && a16(p.out_act) && a16(p.res) && a16(p.gate) &&
+                 a16(p.scale) && a16(p.shift)) ? 1 : 0;
+    static_assert(2 * BM * (BK + 1) + 2 * BK * BN >= WM * WN * 32 * 36, "the epilogue patches must fit the A / B buffers");
+    const long long padded = (long long)((q.mblocks + 7) / 8) * 8 * q.nblocks;
+    q.raster = (raster && q.nblocks > 1 && padded <= 0x7fffffffLL) ? 1 : 0;
+    dim3 grid = q.raster ? dim3((unsigned)padded) : dim3(q.mblocks, q.nblocks);
+    hipLaunchKernelGGL(kern, grid, dim3(WM * WN * 64), smem, st, q);
     return hipGetLastError();
 }

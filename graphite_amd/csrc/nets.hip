@@ -567,6 +567,11 @@ __global__ void k_argmax_hits(const float* __restrict__ logits, int N, int ncls,
 // ---------------------------------------------------------------------------------------------
 static bool use_igemm_convs();
 static bool small_launch_ok();
+static bool prof_shapes() {          // GRAPHITE_PROF_SHAPES=1: profile entries of the igemm kernel carry the GEMM shape (tuning runs)
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("GRAPHITE_PROF_SHAPES"); v = (e && e[0] == '1') ? 1 : 0; }
+    return v == 1;
+}
 static int halo_variant(int layer);
 static int bf16_variant(int layer);
 
@@ -678,6 +683,10 @@ static int run_conv(gr_ctx* ctx, const Layer& L, const float* in, int B, int H, 
     }
 #define GO(BK_, WM_, WN_, TM_, TN_, POOL_)                                                                        \
     do {                                                                                                          \
+        if (prof_shapes())                                                                                        \
+            snprintf(pname, sizeof(pname), "igemm<%d,%d,%d,%d,%d,%d> M%d K%d N%d k%ds%d", BK_, WM_, WN_, TM_, TN_,     \
+                     (int)POOL_, p.M, K, L.Cout, L.KH, L.stride);                                                \
+        else                                                                                                      \
         snprintf(pname, sizeof(pname), "k_conv_igemm<%d,%d,%d,%d,%d,%d>", BK_, WM_, WN_, TM_, TN_, (int)POOL_);      \
         ProfScope ps_(ctx, pname, st, flops, bytes);                                                              \
         e = launch_conv_igemm<BK_, WM_, WN_, TM_, TN_, POOL_>(p, st);                                             \
