@@ -479,7 +479,7 @@ def main():
             all_ms = sum(v["ms"] for v in convs.values())
             all_fl = sum(v["flops"] for v in convs.values())
             traffic, tsrc = None, None
-            for tfile in ("r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+            for tfile in ("r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
                 try:        # HBM bytes per launch of this kernel from the committed rocprofv3 PMC passes (same chunk size)
                     pm = json.load(open(os.path.join(ROOT, "profiles", tfile)))["kernels"].get(name)
                     if pm and pm["images_per_launch"] == args.chunk:
@@ -497,7 +497,7 @@ def main():
         if w and w["ms"] > 0:
             gbs = w["bytes"] / (w["ms"] * 1e-3) / 1e9
             wtr = None
-            for tfile in ("r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+            for tfile in ("r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
                 try:
                     wtr = json.load(open(os.path.join(ROOT, "profiles", tfile)))["kernels"].get("k_warp_net")
                     if wtr:

@@ -194,18 +194,31 @@ __global__ __launch_bounds__(WM* WN * 64) void k_conv_igemm(ConvParams p) {
         if (kc + 1 < nchunk) load_chunk(kc + 1);
         const float* a = As + buf * BM * LDA + (wm * TM * 32 + lp) * LDA + lh;
         const float* b = Bs + buf * BK * BN + lh * BN + wn * TN * 32 + lp;
+        // The fragments of k-pair kk+1 are read BEFORE the MFMAs of k-pair kk are issued (two register sets), and a
+        // scheduling barrier keeps the compiler from sinking the reads back down to their use: left alone it reads a
+        // k-pair's fragments, waits for the LDS (lgkmcnt(0)) and only then issues that pair's MFMAs -- a full LDS latency
+        // exposed per 4 MFMAs with two waves per SIMD to cover it (108 TFLOP/s on the plain GEMM shapes).
+        float av[2][TM], bv[2][TN];
+#pragma unroll
+        for (int i = 0; i < TM; i++) av[0][i] = a[i * 32 * LDA];
+#pragma unroll
+        for (int j = 0; j < TN; j++) bv[0][j] = b[j * 32];
 #pragma unroll
         for (int kk = 0; kk < BK / 2; kk++) {
-            float av[TM], bv[TN];
+            const int cur = kk & 1, nxt = cur ^ 1;
+            if (kk + 1 < BK / 2) {
 #pragma unroll
-            for (int i = 0; i < TM; i++) av[i] = a[i * 32 * LDA + 2 * kk];
+                for (int i = 0; i < TM; i++) av[nxt][i] = a[i * 32 * LDA + 2 * (kk + 1)];
 #pragma unroll
-            for (int j = 0; j < TN; j++) bv[j] = b[2 * kk * BN + j * 32];
+                for (int j = 0; j < TN; j++) bv[nxt][j] = b[2 * (kk + 1) * BN + j * 32];
+            }
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int i = 0; i < TM; i++)
 #pragma unroll
                 for (int j = 0; j < TN; j++)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[cur][i], bv[cur][j], acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
         }
         if (kc + 1 < nchunk) store_chunk(buf ^ 1);
         __syncthreads();

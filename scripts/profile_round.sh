@@ -9,6 +9,8 @@ timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/ben
 rm -f $O/bench/*kernel_trace.csv
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/wrn -o wrn -- python3 $R/scripts/tune_wrn.py 1024 > $O/wrn_under_rocprof.log 2> $O/wrn.err || exit 1
 rm -f $O/wrn/*kernel_trace.csv
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/bagnet -o bagnet -- python3 $R/scripts/tune_bagnet.py 128 > $O/bagnet_under_rocprof.log 2> $O/bagnet.err || echo non-fatal
+rm -f $O/bagnet/*kernel_trace.csv
 pass() {   # name, counters, program...
   local name=$1 ctr=$2; shift 2
   timeout -s KILL 150 rocprofv3 --pmc $ctr --output-format csv -d $O/$name -o $name -- python3 "$@" > $O/$name.log 2>&1 || { echo "pass $name failed"; return 1; }
