@@ -466,9 +466,12 @@ def main():
         "tr_queries_per_s": C_total * args.steps / dt,
         "hits_checksum": int(hits.sum().item()),
     }
-    seen = ranks_seen(world, rank, dev, backend)
-    out["ranks_seen"] = seen
-    out["distinct_devices_seen"] = len({(r["uuid"], r["pci_bus_id"]) for r in seen})
+    try:                    # evidence for "did the collective backend really connect N ranks"; must never cost the line
+        seen = ranks_seen(world, rank, dev, backend)
+        out["ranks_seen"] = seen
+        out["distinct_devices_seen"] = len({(r["uuid"], r["pci_bus_id"]) for r in seen})
+    except Exception as e:      # noqa: BLE001
+        out["ranks_seen"] = {"error": "%s: %s" % (type(e).__name__, e)}
 
     if rank == 0 and prof:
         convs = {k: v for k, v in prof.items() if k.startswith("k_conv") and v["ms"] > 0}
