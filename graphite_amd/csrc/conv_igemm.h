@@ -336,7 +336,9 @@ __global__ __launch_bounds__(WM* WN * 64) void k_conv_igemm(ConvParams p) {
 template <int BK, int WM, int WN, int TM, int TN, bool POOL>
 static inline hipError_t launch_conv_igemm(const ConvParams& p, hipStream_t st) {
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
-    constexpr size_t smem = sizeof(float) * (2 * BM * (BK + 1) + 2 * BK * BN);
+    constexpr size_t smem_ab = sizeof(float) * (2 * BM * (BK + 1) + 2 * BK * BN);
+    constexpr size_t smem_ep = sizeof(float) * (WM * WN * 32 * 36);          // the epilogue's per-wave patches reuse the buffers
+    constexpr size_t smem = smem_ab > smem_ep ? smem_ab : smem_ep;
     auto kern = k_conv_igemm<BK, WM, WN, TM, TN, POOL>;
     // the attribute is per device: one flag per device this process launches on
     static bool attr_set[64] = {false};
@@ -358,7 +360,6 @@ static inline hipError_t launch_conv_igemm(const ConvParams& p, hipStream_t st) 
     if (vec < 0) { const char* e = getenv("GRAPHITE_IGEMM_VEC"); vec = (e && e[0] == '0') ? 0 : 1; }
     q.vec_epi = (vec && !POOL && p.Cout % 4 == 0 && a16(p.out_raw) && a16(p.out_act) && a16(p.res) && a16(p.gate) &&
                  a16(p.scale) && a16(p.shift)) ? 1 : 0;
-    static_assert(2 * BM * (BK + 1) + 2 * BK * BN >= WM * WN * 32 * 36, "the epilogue patches must fit the A / B buffers");
     const long long padded = (long long)((q.mblocks + 7) / 8) * 8 * q.nblocks;
     q.raster = (raster && q.nblocks > 1 && padded <= 0x7fffffffLL) ? 1 : 0;
     dim3 grid = q.raster ? dim3((unsigned)padded) : dim3(q.mblocks, q.nblocks);

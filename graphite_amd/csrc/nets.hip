@@ -698,20 +698,30 @@ static int run_conv(gr_ctx* ctx, const Layer& L, const float* in, int B, int H, 
     if (small_launch_ok() && p.M <= 4096 && bk == 32 && !pool && L.KH == 1 && L.KW == 1 && H == 1 && W == 1 && L.NP % 32 == 0 && !L.kchunk) {
         GO(32, 4, 1, 1, 1, false);
     } else
-    if (bn == 32) {
-        if (bk == 32) { if (pool) GO(32, 4, 1, 2, 1, true); else GO(32, 4, 1, 2, 1, false); }
-        else if (bk == 16 && !pool) GO(16, 4, 1, 2, 1, false);
-        else if (bk == 20 && !pool) GO(20, 4, 1, 2, 1, false);
-        else if (bk == 12 && !pool) GO(12, 4, 1, 2, 1, false);
-    } else if (bn == 64) {
-        if (bk == 32) { if (pool) GO(32, 2, 2, 2, 1, true); else GO(32, 2, 2, 2, 1, false); }
-        else if (bk == 16 && !pool) GO(16, 2, 2, 2, 1, false);
-    } else if (bn == 128) {
-        if (bk == 32) { if (pool) GO(32, 2, 2, 2, 2, true); else GO(32, 2, 2, 2, 2, false); }
-        else if (bk == 16 && !pool) GO(16, 2, 2, 2, 2, false);
-    } else if (bn == 160) {
-        if (bk == 32 && !pool) GO(32, 4, 1, 1, 5, false);
-        else if (bk == 16 && !pool) GO(16, 4, 1, 1, 5, false);
+    {
+        // K chunk: 16 wherever the layer allows it.  The kernel holds ~170 registers (3 waves per SIMD at most), and with
+        // BK = 32 its LDS buffers (67 KB for the 128 x 128 tile) allow only 2 workgroups per CU; BK = 16 halves them, so a
+        // third workgroup covers the others' barriers: fc5 / fc6 111 -> 121 TFLOP/s, BagNet-17 90 -> 101 TFLOP/s
+        // (gpurun_out/r3e/igemm_variants*.txt; BK = 8 and 256-wide N tiles measured slower).  Channel-chunked layers
+        // (kchunk) and the pooled instantiations keep BK = 32.  GRAPHITE_IGEMM_VARIANT=9: BK = 32 everywhere (A/B runs).
+        static int gv = -1;
+        if (gv < 0) { const char* e = getenv("GRAPHITE_IGEMM_VARIANT"); gv = e ? atoi(e) : 0; }
+        const bool k16 = (bk == 16) || (bk == 32 && !pool && !L.kchunk && gv != 9);
+        if (bn == 32) {
+            if (bk == 32) { if (pool) GO(32, 4, 1, 2, 1, true); else GO(32, 4, 1, 2, 1, false); }   // 32-wide N (fc7, BagNet's fc): BK = 32 measured faster
+            else if (bk == 16 && !pool) GO(16, 4, 1, 2, 1, false);
+            else if (bk == 20 && !pool) GO(20, 4, 1, 2, 1, false);
+            else if (bk == 12 && !pool) GO(12, 4, 1, 2, 1, false);
+        } else if (bn == 64) {
+            if (k16 && !pool) { if (gv == 1) GO(16, 2, 2, 2, 1, false); else GO(16, 4, 2, 2, 1, false); }
+            else if (bk == 32) { if (pool) GO(32, 2, 2, 2, 1, true); else GO(32, 2, 2, 2, 1, false); }
+        } else if (bn == 128) {
+            if (k16 && !pool) { if (gv == 1) GO(16, 2, 2, 2, 2, false); else GO(16, 4, 2, 2, 2, false); }
+            else if (bk == 32) { if (pool) GO(32, 2, 2, 2, 2, true); else GO(32, 2, 2, 2, 2, false); }
+        } else if (bn == 160) {
+            if (k16 && !pool) GO(16, 4, 1, 1, 5, false);
+            else if (bk == 32 && !pool) GO(32, 4, 1, 1, 5, false);
+        }
     }
 #undef GO
     if (e != hipSuccess) return gr_fail(ctx, GR_EHIP, "conv launch (bn=%d bk=%d pool=%d): %s", bn, bk, (int)pool, hipGetErrorString(e));
