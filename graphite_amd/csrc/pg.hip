@@ -139,20 +139,25 @@ int pg_preprocess(gr_ctx* ctx, const float* x, int N, int S, int D, bool in_nhwc
 // u = max(local, 0) in LDS; per class c: total_c (sequential row-major sum), win_c = max over window positions of the
 // window's sequential row-major sum; masked_c = win_c / total_c > thres ? total_c - win_c : total_c; pred = LAST maximum.
 // Window sums are >= 0, so their float order is their int order: one LDS atomicMax per (window, class).
+// STAGED: the clipped map of the image sits in LDS (bagnet17: 19 KB); maps too large for that are clipped on the fly from
+// global memory (L2), same sums in the same order.
+template <bool STAGED>
 __global__ __launch_bounds__(256) void k_pg_masking(const float* __restrict__ local, int h, int w, int ncls, int wx, int wy,
                                                     float thres, float* __restrict__ scores, long long* __restrict__ preds) {
-    extern __shared__ float u[];                 // [h*w*ncls] + totals[ncls] + winmax[ncls] (int bits)
-    float* tot = u + h * w * ncls;
-    int* wmax = reinterpret_cast<int*>(tot + ncls);
+    extern __shared__ float smem_pg[];           // [STAGED: h*w*ncls] + totals[ncls] + winmax[ncls] (int bits)
     const int tid = threadIdx.x, n = blockIdx.x, npos = h * w;
     const float* src = local + (size_t)n * npos * ncls;
-    for (int i = tid; i < npos * ncls; i += 256) { float v = src[i]; u[i] = v > 0.f ? v : 0.f; }
+    float* tot = smem_pg + (STAGED ? npos * ncls : 0);
+    int* wmax = reinterpret_cast<int*>(tot + ncls);
+    auto u = [&](int i) { if (STAGED) return smem_pg[i]; const float v = src[i]; return v > 0.f ? v : 0.f; };
+    if (STAGED)
+        for (int i = tid; i < npos * ncls; i += 256) { float v = src[i]; smem_pg[i] = v > 0.f ? v : 0.f; }
     if (tid < ncls) wmax[tid] = 0;               // bits of +0.0f; every window sum is >= 0
     __syncthreads();
-    if (tid < ncls) {
+    for (int c = tid; c < ncls; c += 256) {
         float s = 0.f;
-        for (int p = 0; p < npos; p++) s += u[p * ncls + tid];
-        tot[tid] = s;
+        for (int p = 0; p < npos; p++) s += u(p * ncls + c);
+        tot[c] = s;
     }
     const int nwx = h - wx + 1, nwy = w - wy + 1;
     for (int i = tid; i < nwx * nwy * ncls; i += 256) {
@@ -160,11 +165,11 @@ __global__ __launch_bounds__(256) void k_pg_masking(const float* __restrict__ lo
         const int x0 = wi / nwy, y0 = wi % nwy;
         float s = 0.f;
         for (int a = 0; a < wx; a++)
-            for (int b = 0; b < wy; b++) s += u[((x0 + a) * w + y0 + b) * ncls + c];
+            for (int b = 0; b < wy; b++) s += u(((x0 + a) * w + y0 + b) * ncls + c);
         atomicMax(&wmax[c], __float_as_int(s));
     }
     __syncthreads();
-    if (tid == 0) {
+    if (tid == 0) {                              // sequential on purpose: the last-maximum rule
         int best = 0;
         float bv = 0.f;
         for (int c = 0; c < ncls; c++) {
@@ -180,12 +185,15 @@ __global__ __launch_bounds__(256) void k_pg_masking(const float* __restrict__ lo
 int pg_masking(gr_ctx* ctx, const float* local, int N, int h, int w, int ncls, int wx, int wy, float thres, float* scores,
                int64_t* preds, hipStream_t st) {
     if (N <= 0) return GR_OK;
-    if (h <= 0 || w <= 0 || ncls <= 0 || ncls > 256 || wx <= 0 || wy <= 0 || wx > h || wy > w)
+    if (h <= 0 || w <= 0 || ncls <= 0 || ncls > 4096 || wx <= 0 || wy <= 0 || wx > h || wy > w || (long long)h * w * ncls > 0x7fffffffLL)
         return gr_fail(ctx, GR_EINVAL, "masking_defense: bad shape %dx%dx%d, window %dx%d", h, w, ncls, wx, wy);
-    const size_t smem = sizeof(float) * ((size_t)h * w * ncls + 2 * ncls);
-    if (smem > 64 * 1024) return gr_fail(ctx, GR_EINVAL, "masking_defense: local logits of %zu bytes per image exceed 64 KB of LDS", smem);
+    const size_t staged = sizeof(float) * ((size_t)h * w * ncls + 2 * ncls);
     ProfScope ps_(ctx, "k_pg_masking", st, 0.0, 4.0 * N * ((double)h * w * ncls + ncls));
-    hipLaunchKernelGGL(k_pg_masking, dim3(N), dim3(256), smem, st, local, h, w, ncls, wx, wy, thres, scores, (long long*)preds);
+    if (staged <= 64 * 1024)
+        hipLaunchKernelGGL(k_pg_masking<true>, dim3(N), dim3(256), staged, st, local, h, w, ncls, wx, wy, thres, scores, (long long*)preds);
+    else
+        hipLaunchKernelGGL(k_pg_masking<false>, dim3(N), dim3(256), sizeof(float) * 2 * ncls, st, local, h, w, ncls, wx, wy, thres, scores,
+                           (long long*)preds);
     GR_HIP(ctx, hipGetLastError());
     return GR_OK;
 }

@@ -201,7 +201,8 @@ int gr_pg_out_size(const gr_model* m);
 /* local logits (:44): x [N,3,32,32] dev -> local [N,h,h,ncls] dev */
 int gr_pg_local_logits(gr_ctx* ctx, gr_model* m, const float* x, int N, float* local, void* stream);
 /* masking_defense (:48) on caller-supplied local logits [N,h,w,ncls] dev (any local-logit net can sit in front):
- * scores [N,ncls] dev = masked class evidence, preds [N] int64 dev; either may be NULL.  h*w*ncls*4 <= 64 KB. */
+ * scores [N,ncls] dev = masked class evidence, preds [N] int64 dev; either may be NULL.  Maps of up to 64 KB per image
+ * are staged in LDS, larger ones are read from global memory (same sums, same order). */
 int gr_pg_masking_defense(gr_ctx* ctx, const float* local, int N, int h, int w, int ncls, int window, float thres,
                           float* scores, int64_t* preds, void* stream);
 
