@@ -1,5 +1,5 @@
-// gemm_bf16.h -- C[M][N] = act(A[M][K] * W + bias) on v_mfma_f32_32x32x16_bf16, for GTSRBNet's fc5 / fc6 in the bf16
-// throughput mode (GR_PREC_BF16; not the parity path).
+// gemm_bf16.h -- C[M][N] = act(A[M][K] * W + bias [+ res]) on v_mfma_f32_32x32x16_bf16, for GTSRBNet's fc5 / fc6 and
+// BagNet's stride-1 1x1 convs in the bf16 throughput mode (GR_PREC_BF16; not the parity path).
 //   A: f32 row-major activations, rounded to bf16 (nearest even) while a BM x BK stage goes global -> registers -> LDS
 //      (row stride BK*2+16 bytes = an odd number of 16-byte slots: conflict-free ds_read_b128 fragments).
 //   W: bf16, packed at load in fragment order [K/16][N/32][2][32][8] (conv_halo_bf16.h), staged the same way.
@@ -16,6 +16,7 @@ struct GemmBfParams {
     const float* bias;      // [N]
     void* c;                // [M][N] f32, or bf16 (OUT_BF)
     int M, N, K, relu;
+    const float* res;       // [M][N] f32 residual added before the ReLU, or null (BagNet's bottleneck blocks)
 };
 
 template <int WM, int WN, int TM, int TN, int BK, bool IN_BF, bool OUT_BF>
@@ -150,7 +151,7 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void k_gemm_bf16(GemmBfParams p) {
 #pragma unroll
                 for (int r = 0; r < 16; r++) {
                     float v = acc[i][j][r] + bias;
-                    if (p.relu) v = v > 0.f ? v : 0.f;
+                    if (p.relu && !p.res) v = v > 0.f ? v : 0.f;
                     *reinterpret_cast<float*>(patch + ((r & 3) + 8 * (r >> 2) + 4 * lh) * EROW + lp * 4) = v;
                 }
                 asm volatile("" ::: "memory");
@@ -167,6 +168,17 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void k_gemm_bf16(GemmBfParams p) {
                     const int m = mb + prow + RPP * it;
                     if (m >= p.M) continue;
                     const size_t off = (size_t)m * p.N + nb + cg * CPV;
+                    if (p.res) {                                     // (acc + bias) + res, then the ReLU: conv_igemm.h's order
+#pragma unroll
+                        for (int q = 0; q < (OUT_BF ? 2 : 1); q++) {
+                            const f32x4v rv = *reinterpret_cast<const f32x4v*>(p.res + off + 4 * q);
+#pragma unroll
+                            for (int e = 0; e < 4; e++) {
+                                float v = pv[it][q][e] + rv[e];
+                                pv[it][q][e] = (p.relu && !(v > 0.f)) ? 0.f : v;
+                            }
+                        }
+                    }
                     if constexpr (OUT_BF) {
                         bf16x8 h;
 #pragma unroll

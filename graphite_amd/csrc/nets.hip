@@ -386,7 +386,10 @@ static int make_layer_bn(gr_model* m, Layer* L, const float* w, const float* con
         sh[o] = bn[1][o] - bn[2][o] * sc;
         for (size_t e = 0; e < (size_t)Ci * K * K; e++) ws[(size_t)o * Ci * K * K + e] = w[(size_t)o * Ci * K * K + e] * sc;
     }
-    return make_layer(m, L, ws.data(), sh.data(), Co, Ci, K, K, stride, 0);
+    int rc = make_layer(m, L, ws.data(), sh.data(), Co, Ci, K, K, stride, 0);
+    // bf16 throughput mode: stride-1 1x1 convs are plain GEMMs over the NHWC rows (gemm_bf16.h); the FOLDED weights are rounded
+    if (!rc && K == 1 && stride == 1 && Ci % 32 == 0 && Co % 64 == 0) rc = make_fc_bf16(m, L, ws.data(), Co, Ci);
+    return rc;
 }
 
 extern "C" int gr_model_load_bagnet(gr_ctx* ctx, const float* const* t, const int64_t* numel, int n, const int* layers,
@@ -473,7 +476,7 @@ extern "C" int gr_model_num_classes(const gr_model* m) { return m ? m->ncls : GR
 extern "C" int gr_model_set_precision(gr_model* m, int precision) {
     if (!m) return GR_EINVAL;
     if (precision != GR_PREC_F32 && precision != GR_PREC_BF16) return gr_fail(m->ctx, GR_EINVAL, "gr_model_set_precision: %d", precision);
-    if (precision == GR_PREC_BF16 && m->kind != 1) {
+    if (precision == GR_PREC_BF16 && m->kind == 2) {
         bool any = false;
         for (const WrnBlock& b : m->blocks) any = any || b.conv1.wbf || b.conv2.wbf;
         if (!any) return gr_fail(m->ctx, GR_EINVAL, "gr_model_set_precision: this WideResNet has no layer the bf16 kernels cover "
@@ -924,7 +927,7 @@ static int run_gtsrb_halo_bf16(gr_ctx* ctx, const Layer& L, int layer, const flo
 static int run_fc_bf16(gr_ctx* ctx, const Layer& L, const char* name, const float* in, int M, float* out, hipStream_t st,
                        bool in_bf = false, bool out_bf = false) {
     GemmBfParams p;
-    p.a = in; p.w = L.wbf; p.bias = L.bias; p.c = out; p.M = M; p.N = L.Cout; p.K = L.CinT; p.relu = 1;
+    p.a = in; p.w = L.wbf; p.bias = L.bias; p.c = out; p.M = M; p.N = L.Cout; p.K = L.CinT; p.relu = 1; p.res = nullptr;
     char pname[64];
     snprintf(pname, sizeof(pname), "k_gemm_bf16<%s>", name);
     ProfScope ps_(ctx, pname, st, 2.0 * M * L.Cout * L.CinT, 4.0 * M * (L.CinT + L.Cout) + 2.0 * L.CinT * L.Cout);
@@ -1380,19 +1383,38 @@ int net_pg_local(gr_ctx* ctx, gr_model* m, const float* x, int N, float* local, 
     float* R = T2 + (size_t)N * m->pg_big;
     int rc;
     const int D = m->pg_D;
+    // GR_PREC_BF16 (throughput mode, not the parity path): the stride-1 1x1 convs -- 74 % of bagnet17's flops -- run as bf16
+    // GEMMs with f32 accumulation; activations stay f32 in HBM (rounded while a stage is loaded), the 3x3 convs, the strided
+    // shortcuts and the fc stay on the fp32 kernel.
+    auto conv = [&](const Layer& L, const float* in, int H, const float* res, float* out, bool relu, int out_hw) -> int {
+        if (m->precision == GR_PREC_BF16 && L.wbf && L.KH == 1 && L.stride == 1 && out_hw == 0) {
+            GemmBfParams q;
+            q.a = in; q.w = L.wbf; q.bias = L.bias; q.c = out; q.res = res;
+            q.M = N * H * H; q.N = L.Cout; q.K = L.CinT; q.relu = relu ? 1 : 0;
+            char pname[64];
+            snprintf(pname, sizeof(pname), "k_gemm_bf16<bagnet N%d>", L.Cout >= 128 ? 128 : 64);
+            ProfScope ps_(ctx, pname, st, 2.0 * q.M * q.N * q.K, 4.0 * q.M * ((double)q.K + q.N * (res ? 2 : 1)) + 2.0 * q.K * q.N);
+            hipError_t e;
+            if (L.Cout % 128 == 0) e = q.K % 64 == 0 && q.K >= 128 ? launch_gemm_bf16<2, 2, 2, 2, 64>(q, st) : launch_gemm_bf16<2, 2, 2, 2, 32>(q, st);
+            else e = q.K % 64 == 0 && q.K >= 128 ? launch_gemm_bf16<2, 2, 2, 1, 64>(q, st) : launch_gemm_bf16<2, 2, 2, 1, 32>(q, st);
+            if (e != hipSuccess) return gr_fail(ctx, GR_EHIP, "gemm_bf16 launch (bagnet %dx%d): %s", q.K, q.N, hipGetErrorString(e));
+            return GR_OK;
+        }
+        return run_conv(ctx, L, in, N, H, H, res, nullptr, out, nullptr, relu, false, st, nullptr, GR_PREC_F32, false, false, out_hw);
+    };
     if ((rc = pg_preprocess(ctx, x ? x : x4, N, 32, D, x == nullptr, m->bag_conv1, T1, st))) return rc;
     if ((rc = run_conv(ctx, m->bag_conv2, T1, N, D, D, nullptr, nullptr, X, nullptr, true, false, st))) return rc;
     int H = D - 2;
     for (BagBlock& b : m->bag) {
         const int Ho = (H - b.k) / b.stride + 1;
-        if ((rc = run_conv(ctx, b.c1, X, N, H, H, nullptr, nullptr, T1, nullptr, true, false, st))) return rc;
-        if ((rc = run_conv(ctx, b.c2, T1, N, H, H, nullptr, nullptr, T2, nullptr, true, false, st))) return rc;
+        if ((rc = conv(b.c1, X, H, nullptr, T1, true, 0))) return rc;
+        if ((rc = conv(b.c2, T1, H, nullptr, T2, true, 0))) return rc;
         const float* res = X;
         if (b.has_ds) {             // 1x1 stride-s conv + BN; only the Ho x Ho corner the crop keeps
-            if ((rc = run_conv(ctx, b.ds, X, N, H, H, nullptr, nullptr, R, nullptr, false, false, st, nullptr, GR_PREC_F32, false, false, Ho))) return rc;
+            if ((rc = conv(b.ds, X, H, nullptr, R, false, Ho == (H - 1) / b.stride + 1 ? 0 : Ho))) return rc;
             res = R;
         } else if (Ho != H) return gr_fail(ctx, GR_ESTATE, "bagnet: identity residual of a different size");
-        if ((rc = run_conv(ctx, b.c3, T2, N, Ho, Ho, res, nullptr, T1, nullptr, true, false, st))) return rc;
+        if ((rc = conv(b.c3, T2, Ho, res, T1, true, 0))) return rc;
         float* tmp = X; X = T1; T1 = tmp;
         H = Ho;
     }

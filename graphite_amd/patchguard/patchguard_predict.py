@@ -62,6 +62,12 @@ class PatchGuard:
                                "predict()/forward() are available, not the fused tr_hits path")
         return self._model
 
+    def set_precision(self, precision):
+        """'f32' (default, bit-exact against the oracle) or 'bf16': BagNet's stride-1 1x1 convs (74 % of bagnet17's flops) on
+        bf16 operands with f32 accumulation -- a throughput mode, as for the other classifiers (gr_model_set_precision)."""
+        self.hip_model.set_precision(precision)
+        return self
+
     def local_logits(self, x):
         x = torch.as_tensor(x, dtype=torch.float32)
         if self._net is not None:

@@ -156,7 +156,8 @@ int gr_model_num_classes(const gr_model* m);
  * bf16 rounding boundary round differently in any two implementations, so logits agree to ~1e-2 of the largest logit --
  * the same order as bf16 against fp32 itself (tests/test_gpu_bf16.py has the numbers).  WideResNet: the 3x3 convs (stride 1
  * and 2) with Cin % 32 == 0, Cout % 160 == 0 (95 % of WRN-34-10's flops) run in bf16, the rest stays fp32; GR_EINVAL for a net without
- * such a layer. */
+ * such a layer.  PatchGuard (gr_model_load_bagnet): BagNet's stride-1 1x1 convs (74 % of bagnet17's flops) run as bf16 GEMMs,
+ * activations stay f32 in HBM; 3x3 convs, strided shortcuts, the fc and the masking epilogue stay fp32. */
 #define GR_PREC_F32 0
 #define GR_PREC_BF16 1
 int gr_model_set_precision(gr_model* m, int precision);

@@ -139,3 +139,43 @@ class PatchGuard(nn.Module):
                              for i in range(z.shape[0])])
 
     predict = forward
+
+
+def bagnet_local_logits_folded(sd, z, layers=(3, 4, 6, 3), strides=(2, 2, 2, 1), kernel3=(1, 1, 1, 0), bf16=False):
+    """BagNet forward on a state dict with every conv + eval BatchNorm FOLDED as the HIP library and the C oracle fold them
+    (w' = w * scale[co] in float32, bias' = shift[co]); with bf16=True the stride-1 1x1 convs take activations and folded
+    weights rounded to bfloat16 (nearest even) and accumulate in float64 -- the tolerance reference of the library's
+    GR_PREC_BF16 mode for this net (the matrix cores accumulate in float32; 3x3 convs, strided shortcuts and the fc stay fp32)."""
+    t = {k: torch.as_tensor(v) for k, v in sd.items()}
+
+    def fold(conv, bn):
+        w = t[conv + ".weight"].float()
+        inv = 1.0 / torch.sqrt(t[bn + ".running_var"].float() + 1e-5)
+        sc = t[bn + ".weight"].float() * inv
+        return w * sc.view(-1, 1, 1, 1), t[bn + ".bias"].float() - t[bn + ".running_mean"].float() * sc
+
+    def conv(x, w, b, stride=1):
+        if bf16 and w.shape[-1] == 1 and stride == 1 and w.shape[1] % 32 == 0 and w.shape[0] % 64 == 0:
+            y = F.conv2d(x.bfloat16().double(), w.bfloat16().double(), None, 1).float()
+        else:
+            y = F.conv2d(x, w, None, stride)
+        return y + b.view(1, -1, 1, 1)
+
+    x = F.conv2d(z, t["conv1.weight"].float())
+    w, b = fold("conv2", "bn1")
+    x = F.relu(conv(x, w, b))
+    for g, nblk in enumerate(layers):
+        for i in range(nblk):
+            p = f"layer{g + 1}.{i}"
+            s = strides[g] if i == 0 else 1
+            w, b = fold(p + ".conv1", p + ".bn1"); o = F.relu(conv(x, w, b))
+            w, b = fold(p + ".conv2", p + ".bn2"); o = F.relu(conv(o, w, b, s))
+            w, b = fold(p + ".conv3", p + ".bn3"); o = conv(o, w, b)
+            r = x
+            if i == 0:
+                w, b = fold(p + ".downsample.0", p + ".downsample.1"); r = conv(x, w, b, s)
+            if r.size(-1) != o.size(-1):
+                d = r.size(-1) - o.size(-1)
+                r = r[:, :, :-d, :-d]
+            x = F.relu(o + r)
+    return F.linear(x.permute(0, 2, 3, 1), t["fc.weight"].float(), t["fc.bias"].float())

@@ -11,6 +11,8 @@ from graphite_amd.patchguard.patchguard_predict import PatchGuard
 
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 128
 m = PatchGuard(synth.bagnet_state_dict())
+if len(sys.argv) > 2:
+    m.set_precision(sys.argv[2])           # "bf16": the throughput mode
 x = torch.rand(N, 3, 32, 32, device="cuda") - 0.5
 for _ in range(2):
     m.predict(x)
@@ -22,7 +24,7 @@ torch.cuda.synchronize()
 _hip.profile_enable(False)
 prof = _hip.profile_read()
 tot = sum(v["ms"] for v in prof.values()) / 3
-fl = sum(v["flops"] for k, v in prof.items() if k.startswith("k_conv")) / 3
+fl = sum(v["flops"] for k, v in prof.items() if k.startswith(("k_conv", "k_gemm"))) / 3
 print("N %d: %.2f ms per forward, %.0f images/s, convs %.1f TFLOP/s; checksum %d" % (N, tot, N / tot * 1e3, fl / tot / 1e9, int(p.sum())))
 for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["ms"]):
     print("  %-40s %4d launches %9.3f ms  %6.1f TF  %7.1f GB/s (algorithmic)" % (k, v["launches"] // 3, v["ms"] / 3, v["flops"] / v["ms"] / 1e9 if v["ms"] else 0, v["bytes"] / v["ms"] / 1e6 if v["ms"] else 0))
