@@ -4,6 +4,7 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <array>
+#include <atomic>
 #include <string>
 #include <vector>
 #include "graphite_hip.h"

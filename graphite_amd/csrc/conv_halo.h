@@ -330,7 +330,7 @@ static inline hipError_t launch_conv_halo(const HaloParams& p, hipStream_t st) {
     constexpr size_t smem = tile_b > patch_b ? tile_b : patch_b;
     auto kern = k_conv_halo<CIN, CPH, KH, KW, PS, TH, TW, NIMG, WM, WN, TM, TN, KU, NP, POOL, PIPE>;
     // the attribute is per device: one flag per device this process launches on
-    static bool attr_set[64] = {false};
+    static std::atomic<bool> attr_set[64];
     int dev_ = 0;
     if (hipGetDevice(&dev_) != hipSuccess || dev_ < 0 || dev_ >= 64) return hipErrorInvalidDevice;
     if (!attr_set[dev_]) {

@@ -397,7 +397,7 @@ static inline hipError_t launch_conv_halo_bf16(const HaloBfParams& p, hipStream_
     static_assert(smem <= 160 * 1024, "LDS");
     if (p.H % TH || p.W % TW) return hipErrorInvalidValue;
     auto kern = k_conv_halo_bf16<CIN, COUT, TH, TW, NIMG, WM, WN, TM, TN, KBS, POOL, PF, IN_BF, OUT_BF, PD>;
-    static bool attr_set[64] = {false};                  // the attribute is per device
+    static std::atomic<bool> attr_set[64];                  // the attribute is per device
     int dev_ = 0;
     if (hipGetDevice(&dev_) != hipSuccess || dev_ < 0 || dev_ >= 64) return hipErrorInvalidDevice;
     if (!attr_set[dev_]) {

@@ -319,7 +319,7 @@ static inline hipError_t launch_conv_halo_cc(const HaloCcParams& p, hipStream_t 
     constexpr size_t smem = sizeof(float) * ((size_t)NIMG * (TH + 2 * (KS / 2)) * (TWH * (CC + 1) + RPAD) + 32);
     auto kern = k_conv_halo_cc<KS, CC, TH, TW, NIMG, WM, WN, TM, TN, KU, RP, MODE>;
     // the attribute is per device: one flag per device this process launches on
-    static bool attr_set[64] = {false};
+    static std::atomic<bool> attr_set[64];
     int dev_ = 0;
     if (hipGetDevice(&dev_) != hipSuccess || dev_ < 0 || dev_ >= 64) return hipErrorInvalidDevice;
     if (!attr_set[dev_]) {

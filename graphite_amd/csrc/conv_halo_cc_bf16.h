@@ -282,7 +282,7 @@ static inline hipError_t launch_conv_halo_cc_bf16(const HaloCcBfParams& p, hipSt
     static_assert(smem <= 160 * 1024, "LDS");
     if (p.H % (TH * STRIDE) || p.W % (TW * STRIDE) || p.Cin % 32 || p.Cout % (TN * 32) || (p.out_act && !(p.scale && p.shift))) return hipErrorInvalidValue;
     auto kern = k_conv_halo_cc_bf16<TH, TW, NIMG, WM, TM, TN, OCC, STRIDE, IN_BF, ACT_BF>;
-    static bool attr_set[64] = {false};                  // the attribute is per device
+    static std::atomic<bool> attr_set[64];                  // the attribute is per device
     int dev_ = 0;
     if (hipGetDevice(&dev_) != hipSuccess || dev_ < 0 || dev_ >= 64) return hipErrorInvalidDevice;
     if (!attr_set[dev_]) {

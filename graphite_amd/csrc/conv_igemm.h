@@ -19,6 +19,7 @@
 //   "activated" store relu(v*scale+shift) (folded eval BatchNorm of the NEXT layer, WideResNet).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <atomic>
 #include <stdint.h>
 #include <stdlib.h>
 
@@ -340,8 +341,9 @@ static inline hipError_t launch_conv_igemm(const ConvParams& p, hipStream_t st) 
     constexpr size_t smem_ep = sizeof(float) * (WM * WN * 32 * 36);          // the epilogue's per-wave patches reuse the buffers
     constexpr size_t smem = smem_ab > smem_ep ? smem_ab : smem_ep;
     auto kern = k_conv_igemm<BK, WM, WN, TM, TN, POOL>;
-    // the attribute is per device: one flag per device this process launches on
-    static bool attr_set[64] = {false};
+    // the attribute is per device: one flag per device this process launches on (atomic: two host threads with two contexts
+    // may meet here; setting the attribute twice is harmless)
+    static std::atomic<bool> attr_set[64];
     int dev_ = 0;
     if (hipGetDevice(&dev_) != hipSuccess || dev_ < 0 || dev_ >= 64) return hipErrorInvalidDevice;
     if (!attr_set[dev_]) {

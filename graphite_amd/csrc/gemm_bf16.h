@@ -200,7 +200,7 @@ static inline hipError_t launch_gemm_bf16(const GemmBfParams& p, hipStream_t st)
     static_assert(smem <= 160 * 1024, "LDS");
     if (p.M <= 0 || p.N % BN || p.K % BK || p.K / BK < 2) return hipErrorInvalidValue;
     auto kern = k_gemm_bf16<WM, WN, TM, TN, BK, IN_BF, OUT_BF>;
-    static bool attr_set[64] = {false};                   // the attribute is per device
+    static std::atomic<bool> attr_set[64];                   // the attribute is per device
     int dev_ = 0;
     if (hipGetDevice(&dev_) != hipSuccess || dev_ < 0 || dev_ >= 64) return hipErrorInvalidDevice;
     if (!attr_set[dev_]) {

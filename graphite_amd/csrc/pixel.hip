@@ -1046,7 +1046,7 @@ int px_warp_net(gr_ctx* ctx, const float* att, int H, int W, const gr_xforms* xf
 #define WBK(M)                                                                                                              \
                 do {                                                                                                        \
                     auto kern = k_warp_band<M>;                                                                             \
-                    static bool attr_set[64] = {false};                                                                     \
+                    static std::atomic<bool> attr_set[64];                                                                     \
                     int dev_ = 0;                                                                                           \
                     GR_HIP(ctx, hipGetDevice(&dev_));                                                                       \
                     if (dev_ >= 0 && dev_ < 64 && !attr_set[dev_]) {                                                        \
