@@ -476,17 +476,20 @@ extern "C" int gr_model_predict(gr_ctx* ctx, gr_model* m, const float* x, int N,
 // ---- PatchGuard robust classifier (patchguard/patchguard_predict.py) ----
 extern "C" int gr_pg_preprocess(gr_ctx* ctx, const float* x, int N, int S, int D, float* out, void* stream) {
     NEED_CTX();
+    if (N == 0) return GR_OK;                          // empty batch: nothing to do (pointers may be null)
     if (!x || !out || N < 0) return gr_fail(ctx, GR_EINVAL, "gr_pg_preprocess: bad arguments");
     return pg_preprocess(ctx, x, N, S, D, false, nullptr, out, (hipStream_t)stream);
 }
 extern "C" int gr_pg_masking_defense(gr_ctx* ctx, const float* local, int N, int h, int w, int ncls, int window, float thres,
                                      float* scores, int64_t* preds, void* stream) {
     NEED_CTX();
+    if (N == 0) return GR_OK;
     if (!local || N < 0 || (!scores && !preds)) return gr_fail(ctx, GR_EINVAL, "gr_pg_masking_defense: bad arguments");
     return pg_masking(ctx, local, N, h, w, ncls, window, window, thres, scores, preds, (hipStream_t)stream);
 }
 extern "C" int gr_pg_local_logits(gr_ctx* ctx, gr_model* m, const float* x, int N, float* local, void* stream) {
     NEED_CTX();
+    if (m && N == 0) return GR_OK;
     if (!m || !x || !local || N < 0) return gr_fail(ctx, GR_EINVAL, "gr_pg_local_logits: bad arguments");
     const int h = net_pg_out_size(m);
     if (h <= 0) return gr_fail(ctx, GR_EINVAL, "gr_pg_local_logits: not a PatchGuard model");

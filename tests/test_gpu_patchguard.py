@@ -132,6 +132,21 @@ def test_config5_tr_hits_through_the_robust_classifier_vs_oracle():
     assert p2.cpu().numpy().reshape(-1).tolist() == O.pg_mean_logits(lo).argmax(1).tolist()
 
 
+def test_empty_and_single_batches():
+    sd = synth.bagnet_state_dict("bagnet-t", SMALL["layers"], SMALL["kernel3"], calibrated=False)
+    m = PatchGuard(sd, size=64, **SMALL)
+    e = np.zeros((0, 3, 32, 32), np.float32)
+    assert tuple(_hip.pg_preprocess(e, 64).shape) == (0, 3, 64, 64)
+    assert tuple(m.local_logits(e).shape) == (0, 6, 6, 10)
+    s, p = _hip.pg_masking_defense(np.zeros((0, 6, 6, 10), np.float32), 6, 0.0)
+    assert s.shape[0] == 0 and p.shape[0] == 0
+    x = synth.synth_images("pg-one", 3)
+    one = m.local_logits(x[1:2]).cpu().numpy()
+    assert np.array_equal(one[0], m.local_logits(x).cpu().numpy()[1])       # an image's result does not depend on its batch
+    with pytest.raises(_hip.GraphiteHipError):
+        _hip.pg_masking_defense(np.zeros((2, 6, 6, 10), np.float32), 0, 0.0)   # window of zero
+
+
 def test_patchguard_model_rejects_what_it_cannot_do():
     m = PatchGuard(synth.bagnet_state_dict("bagnet-t", SMALL["layers"], SMALL["kernel3"], calibrated=False), size=64, **SMALL)
     with pytest.raises(_hip.GraphiteHipError):
