@@ -16,6 +16,9 @@ def run():
             os.path.join(INP, "GTSRB/Hulls/14.png"), 14, 27, os.path.join(INP, "GTSRB/Points/14.csv"), "score.py", "Target",
             a.coarse_error, a.reduce_error, 1, 100, 100, model_type='GTSRB', args=a, write_outputs=False)
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 2
+if len(sys.argv) > 2:
+    from graphite_amd import _hip
+    _hip.set_chunk(int(sys.argv[2]))           # images per classifier launch (library default 8192)
 for i in range(n):
     t0 = time.perf_counter(); r = run(); torch.cuda.synchronize()
     print("run %d: %.3f s, %d queries" % (i, time.perf_counter() - t0, r["queries"]))
