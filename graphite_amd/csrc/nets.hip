@@ -871,6 +871,9 @@ static int run_gtsrb_halo_bf16(gr_ctx* ctx, const Layer& L, int layer, const flo
         case 5 * 8 + 2: HBB(128, 128,  8,  8, 2,  2, 4, 2, 1,  8, true ); break;
         case 5 * 8 + 3: HBB(128, 128,  8,  8, 2,  2, 2, 2, 2,  4, true ); break;
         case 5 * 8 + 4: HBB(128, 128,  8,  8, 2,  1, 4, 4, 1,  4, true ); break;
+        case 5 * 8 + 5: HBB(128, 128,  8,  8, 1,  1, 2, 2, 2,  2, true ); break;   // 2 waves x (2 x 2 tiles), 56 KB: 2 workgroups per CU
+        case 5 * 8 + 6: HBP(1, 128, 128,  8,  8, 1,  1, 2, 2, 2,  1, true ); break;   // the same with 8 KB weight stages: 3 workgroups per CU
+        case 5 * 8 + 7: HBB(128, 128,  8,  8, 1,  2, 2, 1, 2,  2, true ); break;   // 4 waves x (1 x 2 tiles)
         default: return gr_fail(ctx, GR_EINVAL, "conv_halo_bf16: no variant %d for layer %d with bf16 links", v, layer);
         }
 #undef HBB
