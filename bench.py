@@ -147,6 +147,21 @@ def extras(_hip, engine, models, synth):
         "conv_frac_of_f32_mfma_peak": cfl / (cms * 1e-3) / 1e12 / PEAK_F32_MFMA if cms else None,
         "kernel_ms": {k: round(v["ms"], 3) for k, v in sorted(p5.items(), key=lambda kv: -kv[1]["ms"])[:8]},
         "hits_checksum": int(h5.sum().item())}
+    try:        # the same launch with BagNet's stride-1 1x1 convs on bf16 operands (throughput mode: labels may differ from fp32)
+        pgm.set_precision("bf16")
+        engine.tr_hits(pgm, i5, m5[:2], t5[:2], x5, 3, pt_file=None, model_type='PATCHGUARD')
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        h5b = engine.tr_hits(pgm, i5, m5, t5, x5, 3, pt_file=None, model_type='PATCHGUARD')
+        torch.cuda.synchronize()
+        dtb = time.perf_counter() - t0
+        res["config5_patchguard_bf16_mode"] = {
+            "images_per_s": C5 * 100 / dtb, "ms_per_launch": 1e3 * dtb, "speedup_vs_f32": dt / dtb,
+            "max_abs_hit_count_diff_vs_f32_of_100": int((h5b - h5).abs().max().item())}
+    except Exception as e:      # noqa: BLE001
+        res["config5_patchguard_bf16_mode"] = {"error": "%s: %s" % (type(e).__name__, e)}
+    finally:
+        pgm.set_precision("f32")
     # the warp stage of the same table alone (what round 2 reported for this config)
     C5w = 512
     masks = np.concatenate([pg["hull"][None], synth.synth_patch_masks("bench-pg", C5w - 1, pg["hull"])])
