@@ -11,6 +11,9 @@
  *   perspective_transform.py:47  cv2.warpPerspective(img, M, (crop_x,crop_y), BORDER_REPLICATE)
  *   GTSRB/GTSRBNet.py:35-52 forward ; cifar/wideresnet.py:25-34, 86-94 forward
  *   utils.py:51-52          argmax == target count
+ *   patchguard/patchguard_predict.py:42-44, 30-32   bicubic x6 + Normalize (torch semantics; checked against torch itself)
+ *   patchguard/patchguard_predict.py:24, 48         BagNet-17 and masking_defense: THIRD-PARTY code (inspire-group/PatchGuard),
+ *                           absent from the reference tree, restated from the publications -- parity unpinned
  * OpenCV 4.2 algorithms (resize / GaussianBlur / warpPerspective+remap / LUT) are restated
  * from the published implementation; marked [OpenCV-recalled, unpinned] where they are used.
  */
