@@ -5,6 +5,7 @@
 // target-hit count is a wavefront-reduction kernel (utils.py:51-52).
 #include "common.h"
 #include "conv_igemm.h"
+#include "fc_small.h"
 #include "conv_halo.h"
 #include "conv_halo_cc.h"
 #include "conv_halo_bf16.h"
@@ -26,6 +27,8 @@ struct Layer {
     int Cin = 0, Cout = 0, NP = 0, KH = 1, KW = 1, stride = 1, pad = 0;
     int CinT = 0;            // true (unpadded) input channels, for the algorithmic flop count
     int kchunk = 0;          // 32: k = (ci/32, ky, kx, ci%32) (stride-1 3x3 convs with Cin % 32 == 0), else k = (ky,kx,ci)
+    const float* wT = nullptr;   // linear layers of GTSRBNet: the transposed copy [Cout (padded)][ldT], k contiguous (= gb[l].w), for fc_small.h
+    int ldT = 0;
     uint16_t* wbf = nullptr; // bf16 copy for conv_halo_bf16.h: [K/16][Cout/32][2][32][8], k = (ky,kx,ci)  (GR_PREC_BF16 only)
 };
 struct BnDev { float* scale = nullptr; float* shift = nullptr; };
@@ -300,6 +303,8 @@ extern "C" int gr_model_load_gtsrb(gr_ctx* ctx, const float* const* t, const int
         rc = make_layer(m, &m->gb[8], wt.data(), nullptr, 1024, 64, 1, 1, 1, 0);
     }
     if (rc) { gr_model_destroy(m); return rc; }
+    // small launches read the linear layers' weights k-contiguous (fc_small.h): that is the transposed layer's [k = co][n = ci]
+    for (int l = 6; l <= 8; l++) { m->g[l].wT = m->gb[l].w; m->g[l].ldT = m->gb[l].NP; }
     *out = m;
     return GR_OK;
 }
@@ -570,6 +575,7 @@ __global__ void k_argmax_hits(const float* __restrict__ logits, int N, int ncls,
 // ---------------------------------------------------------------------------------------------
 static bool use_igemm_convs();
 static bool small_launch_ok();
+static int fc16_max_rows();
 static bool prof_shapes() {          // GRAPHITE_PROF_SHAPES=1: profile entries of the igemm kernel carry the GEMM shape (tuning runs)
     static int v = -1;
     if (v < 0) { const char* e = getenv("GRAPHITE_PROF_SHAPES"); v = (e && e[0] == '1') ? 1 : 0; }
@@ -698,7 +704,28 @@ static int run_conv(gr_ctx* ctx, const Layer& L, const float* in, int B, int H, 
     // leave 8 workgroups walking K with 64 MFMAs per wave and chunk while 248 CUs idle.  128x32 tiles put one 32x32
     // tile on each wave (a quarter of the chain time) and 32 workgroups per 128 rows on the chip.  Same k-ascending
     // chain per output: bit-identical results.
-    if (small_launch_ok() && p.M <= 4096 && bk == 32 && !pool && L.KH == 1 && L.KW == 1 && H == 1 && W == 1 && L.NP % 32 == 0 && !L.kchunk) {
+    const bool small_fc = small_launch_ok() && bk == 32 && !pool && L.KH == 1 && L.KW == 1 && H == 1 && W == 1 && L.NP % 32 == 0 && !L.kchunk;
+    // <= fc16_max_rows(): one 16x16 tile per wave on v_mfma_f32_16x16x4_f32, a chain a quarter as long again (fc_small.h)
+    if (small_fc && p.M <= fc16_max_rows() && (K == 1024 || K == 2048) && L.wT && !res && !gate && !act && out_raw && !out_act &&
+        ((uintptr_t)in & 15) == 0) {
+        static int fv = -1;              // GRAPHITE_FC16_VARIANT: waves per workgroup / stages in flight (tuning runs)
+        if (fv < 0) { const char* ev = getenv("GRAPHITE_FC16_VARIANT"); fv = ev ? atoi(ev) : 0; }
+        snprintf(pname, sizeof(pname), "k_fc_small<v%d>", fv);
+        ProfScope ps_(ctx, pname, st, flops, bytes);
+#define FS(W_, ST_, TM_, TN_) e = K == 1024 ? launch_fc_small<W_, ST_, 1024, TM_, TN_>(p, L.wT, L.ldT, st) \
+                                           : launch_fc_small<W_, ST_, 2048, TM_, TN_>(p, L.wT, L.ldT, st)
+        // measured (scripts/fc_small_check.py, three layers of one forward): 44 us at 100 rows, 94 at 400, 125 at 600 against
+        // 148 us flat on the 32x32x2 tiles; 2 or 4 tiles per wave (fewer operand bytes, longer chains) win nowhere below the
+        // cross-over at ~700 rows
+        switch (fv) {
+        case 0: FS(2, 8, 1, 1); break;
+        case 1: FS(2, 8, 1, 2); break;
+        case 2: FS(2, 8, 2, 1); break;
+        case 3: FS(2, 8, 2, 2); break;
+        default: return gr_fail(ctx, GR_EINVAL, "fc_small: no variant %d", fv);
+        }
+#undef FS
+    } else if (small_fc && p.M <= 4096) {
         GO(32, 4, 1, 1, 1, false);
     } else
     {
@@ -952,6 +979,11 @@ static bool small_launch_ok() {      // GRAPHITE_SMALL=0 turns the small-launch 
     static int v = -1;
     if (v < 0) { const char* e = getenv("GRAPHITE_SMALL"); v = (e && e[0] == '0') ? 0 : 1; }
     return v == 1;
+}
+static int fc16_max_rows() {         // GRAPHITE_FC16_ROWS: largest linear-layer launch (rows) on the 16x16x4 kernel; 0 turns it off
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("GRAPHITE_FC16_ROWS"); v = e ? atoi(e) : 640; if (v < 0) v = 0; }
+    return v;
 }
 static bool use_igemm_convs() {      // GRAPHITE_CONV=igemm selects the im2col-chunk kernels for A/B runs
     static int v = -1;

@@ -25,5 +25,9 @@ for C in (1, 2, 4, 8, 11, 32):
     for _ in range(n): ev.errors(masks, thetas)
     torch.cuda.synchronize()
     _hip.profile_enable(False)
-    ks = sum(v["ms"] for v in _hip.profile_read().values()) / n
+    prof = _hip.profile_read()
+    ks = sum(v["ms"] for v in prof.values()) / n
     print("C=%2d  wall %.3f ms per call, kernels %.3f ms, rest %.3f ms" % (C, wall, ks, wall - ks))
+    if len(sys.argv) > 1:                              # per kernel: microseconds per call (launches per call)
+        for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["ms"]):
+            print("      %-40s %7.1f us  (%g launches)" % (k, v["ms"] / n * 1e3, v["launches"] / n))

@@ -208,6 +208,18 @@ def test_gtsrbnet_ragged_batches(oracle, gtsrb_model, gtsrb_tensors):
         assert np.array_equal(gtsrb_model.forward(torch.from_numpy(x)).cpu().numpy(), orc)
     finally:
         _hip.set_chunk(8192)
+    # linear layers: launches of <= 640 rows run on 16x16x4 MFMA tiles (fc_small.h), larger ones on 32x32x2 tiles --
+    # the same k-ascending chain per logit, so a batch and its slices agree bit for bit on either side of the switch
+    xl = synth.synth_images("gtsrb-ragged-l", 1500)
+    orc_l = oracle.gtsrb_forward(gtsrb_tensors, xl[:700])
+    big = gtsrb_model.forward(torch.from_numpy(xl)).cpu().numpy()
+    assert np.array_equal(big[:700], orc_l)
+    for n in (640, 641, 700):
+        _hip.profile_reset(); _hip.profile_enable(True)
+        lg = gtsrb_model.forward(torch.from_numpy(xl[:n])).cpu().numpy()
+        _hip.profile_enable(False)
+        assert np.array_equal(lg, orc_l[:n])
+        assert any("k_fc_small" in k for k in _hip.profile_read()) == (n <= 640)
     # predict() normalisation quirk (GTSRBNet.py:55-57)
     x01 = (x[:16] + np.float32(0.5)).astype(np.float32)
     renorm = (np.clip(x01, 0, 1) - np.float32(0.5)).astype(np.float32)   # what predict() feeds the net for out-of-range input
