@@ -33,6 +33,9 @@ struct HaloParams {
 // CIN: k extent of one tap; CPH: physical channels per pixel; KH,KW: taps; PS: LDS pixel stride (floats);
 // TH,TW: output tile; NIMG: images per workgroup; WM x WN wavefronts, TM x TN 32x32 tiles each;
 // KU: k-pairs of B prefetched per stage; NP: padded Cout (row length of wgt).
+#ifndef HALO_UB
+#define HALO_UB 0
+#endif
 template <int CIN, int CPH, int KH, int KW, int PS, int TH, int TW, int NIMG, int WM, int WN, int TM, int TN, int KU, int NP,
           bool POOL, int PIPE>
 __global__ __launch_bounds__(WM* WN * 64) void k_conv_halo(HaloParams p) {
@@ -85,7 +88,7 @@ __global__ __launch_bounds__(WM* WN * 64) void k_conv_halo(HaloParams p) {
         constexpr int SEG = CPH / 4;
         constexpr int TOT = NIMG * THH * TWH * SEG;
         constexpr int IT = (TOT + NT - 1) / NT;
-        constexpr int UB = 8;
+        constexpr int UB = HALO_UB > 0 ? HALO_UB : (IT <= 16 ? IT : (IT + 1) / 2);   // loads in flight per thread before the first LDS write
         if (!(p.dbg & 1))
 #pragma unroll
         for (int it0 = 0; it0 < IT; it0 += UB) {

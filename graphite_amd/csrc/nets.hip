@@ -738,7 +738,7 @@ static int run_conv(gr_ctx* ctx, const Layer& L, const float* in, int B, int H, 
         if (gv < 0) { const char* e = getenv("GRAPHITE_IGEMM_VARIANT"); gv = e ? atoi(e) : 0; }
         // Only for launches that give every CU several 256-row workgroups: the whitebox gradient's transposed layers and the
         // attack's small evaluations launch a few thousand rows and keep the 128-row BK = 32 tiles (measured: 0.37 vs 0.41 ms).
-        const bool few256 = ((long long)(p.M + 255) / 256) * (L.NP / bn) < 1024;
+        const bool few256 = ((long long)(p.M + 255) / 256) * (L.NP / bn) < 768;   // 768: fc5 / fc6 of a 32,000-image chunk (1000 workgroups) take the new tile
         const bool k16 = (bk == 16) || (bk == 32 && !pool && !L.kchunk && gv != 9 && !few256);
         if (bn == 32) {
             if (bk == 32) { if (pool) GO(32, 4, 1, 2, 1, true); else GO(32, 4, 1, 2, 1, false); }   // 32-wide N (fc7, BagNet's fc): BK = 32 measured faster
