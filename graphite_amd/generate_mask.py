@@ -171,12 +171,13 @@ def get_heatmap(start_mask, patches, indices, img_v, img_t, lbl_v, lbl_t, model,
     img_v_small = ev.resize(img_v, start_mask.size()[1], start_mask.size()[2])
     if img_t.size()[1] != start_mask.size()[1] or img_t.size()[2] != start_mask.size()[2]:
         img_t = ev.resize(img_t, start_mask.size()[1], start_mask.size()[2])
-    masks, thetas = [], []
-    for p in patches:
-        next_mask = start_mask * (torch.ones(start_mask.size()) - p)
-        masks.append(next_mask)
-        thetas.append((img_t - img_v_small) * next_mask if init_theta is None else init_theta * next_mask)
-    res = ev.errors(masks, thetas)                        # every leave-one-patch-out candidate in one launch
+    if not patches:
+        return [], 0
+    # every leave-one-patch-out candidate in one launch; the same elementwise float32 products as the reference's loop
+    # (generate_mask.py:168-172), taken over the stacked patches
+    masks = start_mask[None] * (torch.ones(start_mask.size())[None] - torch.stack(patches))
+    thetas = ((img_t - img_v_small) if init_theta is None else init_theta)[None] * masks
+    res = ev.errors(masks, thetas)
     return [1 - e for e, _ in res], sum(n for _, n in res)
 
 
@@ -226,7 +227,8 @@ def get_fine_reduced_mask(start_mask, object_size, patches, indices, img_v, img_
             if last_accept:
                 spec_mask = cand                         # assume accepted: the next candidate builds on it
         live = [w for w in window if w[3] is not None]
-        res = ev.errors([w[3] for w in live], [theta_of(w[3]) for w in live]) if live else []
+        live_thetas = {id(w[3]): theta_of(w[3]) for w in live}           # reused by the scoring below
+        res = ev.errors([w[3] for w in live], [live_thetas[id(w[3])] for w in live]) if live else []
         res_it = iter(res)
         # ---- consume in the reference's order; stop at the first outcome that breaks the assumption ----
         consumed = 0
@@ -238,7 +240,7 @@ def get_fine_reduced_mask(start_mask, object_size, patches, indices, img_v, img_
                 continue
             success_rate, query_ct = next(res_it)
             reduction_query_ct += query_ct               # only evaluations the reference would have made
-            theta = theta_of(cand)
+            theta = live_thetas[id(cand)]
             score = scoremod.score_fn(theta + img_v_small, cand, success_rate, object_size, idx, best_score=best_score,
                                       threshold=err_threshold, lbd=lbd)
             if score < best_score:
