@@ -165,6 +165,8 @@ def to_dev(a):
     """float32 contiguous CUDA tensor from numpy / CPU tensor / CUDA tensor."""
     if isinstance(a, np.ndarray):
         a = torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32))
+    elif a.is_cuda and a.dtype == torch.float32 and a.is_contiguous() and a.device.index == torch.cuda.current_device():
+        return a                                    # already in place: the evaluator's calls pass through here twice
     return a.to(device=f"cuda:{device_index()}", dtype=torch.float32).contiguous()
 
 
