@@ -29,8 +29,10 @@ from .evaluator import TREvaluator, make_evaluator
 from .transforms import draw_transforms
 
 scoremod = None
-FINE_WINDOW = 32          # largest speculative window (candidates per launch) in the fine reduction
-FINE_WINDOW_MIN = 4       # the window doubles after a fully consumed launch and halves after a mis-speculation
+FINE_WINDOW = 16          # largest speculative window (candidates per launch) in the fine reduction
+FINE_WINDOW_MIN = 3       # the window doubles after a fully consumed launch and halves after a mis-speculation
+# (16, 3): measured on config 2 (scripts/window_sweep.py, profiles/r03_window_sweep.txt: 0.360 s against 0.369 s at the
+# earlier (32, 4)) and what a replay of the recorded accept / reject sequence under a launch-cost model predicts
 
 
 def _storage_from_bytes(b):
